@@ -1,0 +1,419 @@
+// Batch-norm (+ReLU, +residual) kernels for NHWC bf16 tensors viewed as [M][C].
+//
+// Forward statistics normally come for free from the convolution epilogue
+// (partial per-channel sum / sum-of-squares rows); bn_stats_partials produces
+// the same partial rows for a tensor that did not come out of that kernel.
+// partial_reduce + bn_finalize turn partial rows into mean / invstd /
+// scale / shift (and update the running statistics), bn_apply is the
+// single-pass normalise(+residual)(+ReLU) kernel, and the backward is the
+// classic two-pass form: bn_bwd_partials (per-channel sum(dy), sum(dy*xhat)),
+// bn_bwd_finalize, bn_bwd_apply.
+//
+// All elementwise traffic is 16 bytes per lane (8 bf16 channels); C % 8 == 0.
+#include "common.h"
+
+// ----------------------------------------------------------------------------
+// [R][NV][C] partial rows -> [RS][NV][C]; each output row sums a contiguous
+// slice of input rows in a fixed order (deterministic).
+// ----------------------------------------------------------------------------
+__global__ void partial_reduce_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int NVC,
+                                      int rows_per_split) {
+  int col = blockIdx.x * blockDim.x + threadIdx.x;  // over NV*C
+  int rs = blockIdx.y;
+  if (col >= NVC) return;
+  int r0 = rs * rows_per_split, r1 = r0 + rows_per_split;
+  if (r1 > R) r1 = R;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = r0;
+  for (; r + 4 <= r1; r += 4) {
+    s0 += in[(size_t)r * NVC + col];
+    s1 += in[(size_t)(r + 1) * NVC + col];
+    s2 += in[(size_t)(r + 2) * NVC + col];
+    s3 += in[(size_t)(r + 3) * NVC + col];
+  }
+  for (; r < r1; ++r) s0 += in[(size_t)r * NVC + col];
+  out[(size_t)rs * NVC + col] = (s0 + s1) + (s2 + s3);
+}
+
+extern "C" int dtfa_partial_reduce(const float* in, float* out, int R, int NV, int C, int RS, hipStream_t st) {
+  int NVC = NV * C;
+  int rps = (R + RS - 1) / RS;
+  dim3 grid((NVC + 255) / 256, RS);
+  hipLaunchKernelGGL(partial_reduce_kernel, grid, dim3(256), 0, st, in, out, R, NVC, rps);
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
+// Finalize forward statistics.  part: [R][2][C] (sum, sumsq).  Writes
+// mean/invstd (saved for backward) and the fused scale/shift:
+//   scale = gamma * invstd, shift = beta - mean * scale   (gamma/beta optional)
+// and updates running_mean / running_var in place:
+//   running = running * (1 - momentum) + batch * momentum  (unbiased variance)
+// ----------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C, float count, float eps,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var, float momentum) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int r = 0; r < R; ++r) {
+    s += (double)part[((size_t)r * 2) * C + c];
+    ss += (double)part[((size_t)r * 2 + 1) * C + c];
+  }
+  double mu = s / count;
+  double var = ss / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  float is = (float)(1.0 / sqrt(var + (double)eps));
+  float g = gamma ? gamma[c] : 1.f;
+  float b = beta ? beta[c] : 0.f;
+  float sc = g * is;
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  scale[c] = sc;
+  shift[c] = b - (float)mu * sc;
+  if (run_mean) {
+    double unb = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+    run_mean[c] = run_mean[c] * (1.f - momentum) + (float)mu * momentum;
+    run_var[c] = run_var[c] * (1.f - momentum) + (float)unb * momentum;
+  }
+}
+
+extern "C" int dtfa_bn_finalize(const float* part, int R, int C, float count, float eps, const float* gamma,
+                                const float* beta, float* mean, float* invstd, float* scale, float* shift,
+                                float* run_mean, float* run_var, float momentum, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, R, C, count, eps, gamma,
+                     beta, mean, invstd, scale, shift, run_mean, run_var, momentum);
+  return (int)hipGetLastError();
+}
+
+// Inference-mode scale/shift from running statistics.
+__global__ void bn_eval_coeffs_kernel(int C, float eps, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, const float* __restrict__ run_mean,
+                                      const float* __restrict__ run_var, float* __restrict__ scale,
+                                      float* __restrict__ shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float is = rsqrtf(run_var[c] + eps);
+  float sc = (gamma ? gamma[c] : 1.f) * is;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - run_mean[c] * sc;
+}
+
+extern "C" int dtfa_bn_eval_coeffs(int C, float eps, const float* gamma, const float* beta, const float* rm,
+                                   const float* rv, float* scale, float* shift, hipStream_t st) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, st, C, eps, gamma, beta, rm, rv,
+                     scale, shift);
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
+// z = act(y * scale[c] + shift[c] (+ res))      16 B per lane, grid-stride.
+// ----------------------------------------------------------------------------
+template <bool RELU, bool RES>
+__global__ void bn_apply_kernel(const bf16* __restrict__ y, const bf16* __restrict__ res, bf16* __restrict__ z,
+                                const float* __restrict__ scale, const float* __restrict__ shift, size_t nvec,
+                                int C) {
+  const int cvec = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    int c0 = (int)(i % cvec) << 3;
+    bf16x8 v = *(const bf16x8*)(y + i * 8);
+    bf16x8 r;
+    if (RES) r = *(const bf16x8*)(res + i * 8);
+    float4 sa = *(const float4*)(scale + c0), sb = *(const float4*)(scale + c0 + 4);
+    float4 ha = *(const float4*)(shift + c0), hb = *(const float4*)(shift + c0 + 4);
+    float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+    float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)v[j] * sc[j] + sh[j];
+      if (RES) f += (float)r[j];
+      if (RELU) f = fmaxf(f, 0.f);
+      o[j] = (bf16)f;
+    }
+    *(bf16x8*)(z + i * 8) = o;
+  }
+}
+
+extern "C" int dtfa_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
+                             long long M, int C, int relu, hipStream_t st) {
+  if (C % 8) return -1;
+  size_t nvec = (size_t)M * C / 8;
+  if (nvec == 0) return 0;
+  unsigned blocks = (unsigned)((nvec + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+#define L(R_, S_)                                                                                          \
+  hipLaunchKernelGGL((bn_apply_kernel<R_, S_>), dim3(blocks), dim3(256), 0, st, (const bf16*)y,            \
+                     (const bf16*)res, (bf16*)z, scale, shift, nvec, C)
+  if (relu && res) L(true, true);
+  else if (relu) L(true, false);
+  else if (res) L(false, true);
+  else L(false, false);
+#undef L
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
+// Column partial sums.  Thread block = TX channel-groups (8 channels each) x
+// TY row lanes.  MODE 0: x -> (sum x, sum x^2).  MODE 1 (backward):
+//   g = dz * mask,  mask = (zout > 0) when ReLU else 1
+//   -> (sum g, sum g * xhat),  xhat = (y - mean) * invstd
+// Output rows: [gridDim.y][2][C].
+// ----------------------------------------------------------------------------
+template <int MODE>
+__global__ void col_partials_kernel(const bf16* __restrict__ a, const bf16* __restrict__ yv,
+                                    const bf16* __restrict__ zout, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, float* __restrict__ out, long long M, int C,
+                                    int TX, int rows_per_block, int relu) {
+  extern __shared__ float red[];  // [TY][TX][16]
+  const int TY = blockDim.x / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cg = blockIdx.x * TX + tx;
+  const int cvec = C >> 3;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  if (cg < cvec) {
+    float mu[8], is[8];
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        mu[j] = mean[cg * 8 + j];
+        is[j] = invstd[cg * 8 + j];
+      }
+    }
+    long long r0 = (long long)blockIdx.y * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    for (long long r = r0 + ty; r < r1; r += TY) {
+      size_t off = (size_t)r * C + (size_t)cg * 8;
+      bf16x8 v = *(const bf16x8*)(a + off);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float f = (float)v[j];
+          s1[j] += f;
+          s2[j] += f * f;
+        }
+      } else {
+        bf16x8 yy = *(const bf16x8*)(yv + off);
+        bf16x8 zz;
+        if (relu) zz = *(const bf16x8*)(zout + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float g = (float)v[j];
+          if (relu && !((float)zz[j] > 0.f)) g = 0.f;
+          float xh = ((float)yy[j] - mu[j]) * is[j];
+          s1[j] += g;
+          s2[j] += g * xh;
+        }
+      }
+    }
+  }
+  float* mine = red + ((size_t)ty * TX + tx) * 16;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mine[j] = s1[j];
+    mine[8 + j] = s2[j];
+  }
+  __syncthreads();
+  if (ty == 0 && cg < cvec) {
+    for (int t = 1; t < TY; ++t) {
+      const float* o = red + ((size_t)t * TX + tx) * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s1[j] += o[j];
+        s2[j] += o[8 + j];
+      }
+    }
+    float* dst = out + (size_t)blockIdx.y * 2 * C + (size_t)cg * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dst[j] = s1[j];
+      dst[C + j] = s2[j];
+    }
+  }
+}
+
+static void col_partials_geometry(long long M, int C, int* TX, int* gx, int* gy, int* rpb) {
+  int cvec = C / 8;
+  int tx = 1;
+  while (tx * 2 <= cvec && tx < 64) tx *= 2;
+  *TX = tx;
+  *gx = (cvec + tx - 1) / tx;
+  long long want = 2048 / *gx;
+  if (want < 1) want = 1;
+  long long rows = (M + want - 1) / want;
+  int ty = 256 / tx;
+  if (rows < ty * 4) rows = ty * 4;
+  *rpb = (int)rows;
+  *gy = (int)((M + rows - 1) / rows);
+}
+
+// Rows of partials produced for a given problem (so the caller can size buffers).
+extern "C" int dtfa_col_partials_rows(long long M, int C) {
+  int TX, gx, gy, rpb;
+  col_partials_geometry(M, C, &TX, &gx, &gy, &rpb);
+  return gy;
+}
+
+extern "C" int dtfa_bn_stats_partials(const void* x, float* out, long long M, int C, hipStream_t st) {
+  if (C % 8) return -1;
+  int TX, gx, gy, rpb;
+  col_partials_geometry(M, C, &TX, &gx, &gy, &rpb);
+  hipLaunchKernelGGL((col_partials_kernel<0>), dim3(gx, gy), dim3(256), 256 * 16 * sizeof(float), st,
+                     (const bf16*)x, (const bf16*)nullptr, (const bf16*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, out, M, C, TX, rpb, 0);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dtfa_bn_bwd_partials(const void* dz, const void* y, const void* zout, const float* mean,
+                                    const float* invstd, float* out, long long M, int C, int relu,
+                                    hipStream_t st) {
+  if (C % 8) return -1;
+  int TX, gx, gy, rpb;
+  col_partials_geometry(M, C, &TX, &gx, &gy, &rpb);
+  hipLaunchKernelGGL((col_partials_kernel<1>), dim3(gx, gy), dim3(256), 256 * 16 * sizeof(float), st,
+                     (const bf16*)dz, (const bf16*)y, (const bf16*)zout, mean, invstd, out, M, C, TX, rpb, relu);
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
+// Backward finalize: part [R][2][C] = (sum g, sum g*xhat).
+//   dbeta = sum g ; dgamma = sum g*xhat
+// and the three per-channel coefficients of the elementwise pass
+//   dy = gscale * (g - c1 - xhat*c2),  c1 = sum g / M, c2 = sum g*xhat / M
+//      = ca * g + cb * y + cc
+// ----------------------------------------------------------------------------
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int R, int C, float count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb,
+                                       float* __restrict__ cc, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, sx = 0.0;
+  for (int r = 0; r < R; ++r) {
+    s += (double)part[((size_t)r * 2) * C + c];
+    sx += (double)part[((size_t)r * 2 + 1) * C + c];
+  }
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+  float c1 = (float)(s / count), c2 = (float)(sx / count);
+  float is = invstd[c];
+  float gs = (gamma ? gamma[c] : 1.f) * is;
+  ca[c] = gs;
+  cb[c] = -gs * is * c2;
+  cc[c] = -gs * c1 + gs * is * c2 * mean[c];
+}
+
+extern "C" int dtfa_bn_bwd_finalize(const float* part, int R, int C, float count, const float* gamma,
+                                    const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                    float* ca, float* cb, float* cc, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, R, C, count, gamma,
+                     mean, invstd, dgamma, dbeta, ca, cb, cc, accumulate);
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
+// dy = ca*g + cb*y + cc,  g = dz * mask ; optionally dres = g.
+// ----------------------------------------------------------------------------
+template <bool RELU, bool DRES>
+__global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ y,
+                                    const bf16* __restrict__ zout, bf16* __restrict__ dy, bf16* __restrict__ dres,
+                                    const float* __restrict__ ca, const float* __restrict__ cb,
+                                    const float* __restrict__ cc, size_t nvec, int C) {
+  const int cvec = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    int c0 = (int)(i % cvec) << 3;
+    bf16x8 g8 = *(const bf16x8*)(dz + i * 8);
+    bf16x8 y8 = *(const bf16x8*)(y + i * 8);
+    bf16x8 z8;
+    if (RELU) z8 = *(const bf16x8*)(zout + i * 8);
+    float4 a0 = *(const float4*)(ca + c0), a1 = *(const float4*)(ca + c0 + 4);
+    float4 b0 = *(const float4*)(cb + c0), b1 = *(const float4*)(cb + c0 + 4);
+    float4 d0 = *(const float4*)(cc + c0), d1 = *(const float4*)(cc + c0 + 4);
+    float A[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    float Bc[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float Cc[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    bf16x8 o, r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float g = (float)g8[j];
+      if (RELU && !((float)z8[j] > 0.f)) g = 0.f;
+      o[j] = (bf16)(A[j] * g + Bc[j] * (float)y8[j] + Cc[j]);
+      if (DRES) r[j] = (bf16)g;
+    }
+    *(bf16x8*)(dy + i * 8) = o;
+    if (DRES) *(bf16x8*)(dres + i * 8) = r;
+  }
+}
+
+extern "C" int dtfa_bn_bwd_apply(const void* dz, const void* y, const void* zout, void* dy, void* dres,
+                                 const float* ca, const float* cb, const float* cc, long long M, int C, int relu,
+                                 hipStream_t st) {
+  if (C % 8) return -1;
+  size_t nvec = (size_t)M * C / 8;
+  if (nvec == 0) return 0;
+  unsigned blocks = (unsigned)((nvec + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+#define L(R_, D_)                                                                                            \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<R_, D_>), dim3(blocks), dim3(256), 0, st, (const bf16*)dz,         \
+                     (const bf16*)y, (const bf16*)zout, (bf16*)dy, (bf16*)dres, ca, cb, cc, nvec, C)
+  if (relu && dres) L(true, true);
+  else if (relu) L(true, false);
+  else if (dres) L(false, true);
+  else L(false, false);
+#undef L
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
+// Plain ReLU backward / elementwise add for bf16 (used where no BN is fused).
+// ----------------------------------------------------------------------------
+__global__ void relu_bwd_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ z, bf16* __restrict__ dx,
+                                size_t nvec) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    bf16x8 g = *(const bf16x8*)(dz + i * 8);
+    bf16x8 zz = *(const bf16x8*)(z + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (!((float)zz[j] > 0.f)) g[j] = (bf16)0.f;
+    *(bf16x8*)(dx + i * 8) = g;
+  }
+}
+
+extern "C" int dtfa_relu_bwd(const void* dz, const void* z, void* dx, long long n, hipStream_t st) {
+  if (n % 8) return -1;
+  size_t nvec = (size_t)n / 8;
+  if (!nvec) return 0;
+  unsigned blocks = (unsigned)((nvec + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, st, (const bf16*)dz, (const bf16*)z, (bf16*)dx,
+                     nvec);
+  return (int)hipGetLastError();
+}
+
+__global__ void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ o,
+                                size_t nvec) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    bf16x8 x = *(const bf16x8*)(a + i * 8);
+    bf16x8 y = *(const bf16x8*)(b + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (bf16)((float)x[j] + (float)y[j]);
+    *(bf16x8*)(o + i * 8) = x;
+  }
+}
+
+extern "C" int dtfa_add_bf16(const void* a, const void* b, void* o, long long n, hipStream_t st) {
+  if (n % 8) return -1;
+  size_t nvec = (size_t)n / 8;
+  if (!nvec) return 0;
+  unsigned blocks = (unsigned)((nvec + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(add_bf16_kernel, dim3(blocks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (bf16*)o,
+                     nvec);
+  return (int)hipGetLastError();
+}

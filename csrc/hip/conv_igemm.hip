@@ -1,0 +1,298 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): NHWC bf16 activations,
+// [Cout][tap][Cin] bf16 weights, fp32 MFMA accumulation.
+//
+// One kernel serves forward convolution, data-gradient (run as a convolution
+// of dY with a permuted weight matrix, one launch per output-stride phase) and
+// dense layers (1x1 convolution over a [B,1,1,C] tensor).  The geometry is
+// described by a *tap table*: tap t reads the input pixel
+//     (oy*isy + dy[t], ox*isx + dx[t])
+// for logical output pixel (oy, ox), and the result is written to physical
+// output pixel (oy*osy + oy0, ox*osx + ox0).  Out-of-image taps read zeros.
+//
+// GEMM view:  D[m][n] = sum_k A[m][k] * W[n][k]
+//     m = (b, oy, ox)      rows   -> MFMA A operand (pixels)
+//     n = cout             cols   -> MFMA B operand (weights)
+//     k = (tap, cin)       reduction, Cin % 8 == 0 so a 16-byte chunk never
+//                          straddles a tap
+//
+// Structure: 256 threads = 4 waves in a 2x2 grid, each wave owns a
+// (BM/2)x(BN/2) tile made of 32x32 MFMA blocks (v_mfma_f32_32x32x16_bf16).
+// Operand tiles go global -> LDS with LDS-DMA (global_load_lds_dwordx4); the
+// im2col gather is expressed in the per-lane *source* address, padding is a
+// read from a zero page, and the LDS image is XOR-swizzled through the source
+// chunk choice so that ds_read_b128 fragment reads are bank-conflict free.
+// Two LDS stages: the loads of k-tile t+1 are in flight while tile t is
+// multiplied.  The epilogue optionally adds a bias, applies ReLU, emits
+// per-channel sum / sum-of-squares partials for a following batch-norm, and
+// stores bf16 rows through LDS so that global stores are 16 B per lane.
+#include "common.h"
+
+struct ConvArgs {
+  const bf16* x;
+  const bf16* w;
+  bf16* y;
+  const float* bias;   // [Cout] or null
+  float* stats;        // [mtiles*2][2][Cout] partial (sum, sumsq) or null
+  const bf16* zero;    // >= 16 bytes of zeros, 16-byte aligned
+  const int* taps;     // T entries, (dy << 16) | (dx & 0xffff)
+  int IH, IW, Cin;
+  int OH, OW, Cout;
+  int OYn, OXn;
+  int osy, osx, oy0, ox0;
+  int isy, isx;
+  int T, M, K;
+  unsigned cin_magic;  // ceil(2^32 / Cin)
+  int relu;
+  int dense_out;       // output pixel index == m (no stride/offset mapping)
+};
+
+#define MAX_TAPS 64
+
+template <int BK>
+__device__ __forceinline__ int swz_of_row(int row) {
+  constexpr int S = BK / 8;
+  constexpr int R = 256 / (BK * 2);
+  return (row / R) & (S - 1);
+}
+
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+  constexpr int S = BK / 8;            // 16-byte slots per LDS row
+  constexpr int ROWB = BK * 2;         // bytes per LDS row
+  constexpr int RPI = 1024 / ROWB;     // rows covered by one wave-instruction
+  constexpr int NA = BM * ROWB / 4096; // LDS-DMA instructions per thread (A)
+  constexpr int NB = BN * ROWB / 4096;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int MT = WM / 32, NT = WN / 32;
+  constexpr int KS = BK / 16;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int EP_PITCH = WN * 2 + 16;
+  static_assert(NA >= 1 && NB >= 1, "tile too small for 256-thread staging");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* lds_taps = (int*)smem;
+  char* lds_tiles = smem + MAX_TAPS * 4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+
+  const unsigned mtiles = (p.M + BM - 1) / BM;
+  const unsigned ntiles = (p.Cout + BN - 1) / BN;
+  const unsigned bid = xcd_remap(blockIdx.x, mtiles * ntiles);
+  const unsigned tile_m = bid / ntiles, tile_n = bid % ntiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  if (tid < p.T) lds_taps[tid] = p.taps[tid];
+
+  // ---- per-thread staging rows (fixed across the K loop) ----
+  const int slot = lane % S;
+  const int row_in_inst = lane / S;
+  const int cslot = slot ^ swz_of_row<BK>(wid * RPI + row_in_inst);  // same for every i
+
+  const bf16* abase[NA];
+  int aiy[NA], aix[NA];
+  const int opix = p.OYn * p.OXn;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    int m = m0 + (i * 4 + wid) * RPI + row_in_inst;
+    if (m < p.M) {
+      int b = m / opix;
+      int rem = m - b * opix;
+      int oy = rem / p.OXn;
+      int ox = rem - oy * p.OXn;
+      aiy[i] = oy * p.isy;
+      aix[i] = ox * p.isx;
+      abase[i] = p.x + (size_t)b * p.IH * p.IW * p.Cin;
+    } else {
+      aiy[i] = -(1 << 24);
+      aix[i] = 0;
+      abase[i] = p.x;
+    }
+  }
+  const bf16* bbase[NB];
+  bool bok[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    int n = n0 + (i * 4 + wid) * RPI + row_in_inst;
+    bok[i] = n < p.Cout;
+    bbase[i] = p.w + (size_t)(bok[i] ? n : 0) * p.K;
+  }
+
+  __syncthreads();  // tap table visible
+
+  auto stage = [&](int kt, int buf) {
+    char* sa = lds_tiles + buf * STAGE;
+    char* sb = sa + BM * ROWB;
+    const int kc8 = kt * BK + cslot * 8;
+    const bool kvalid = kc8 < p.K;
+    const int tap = (int)__umulhi((unsigned)kc8, p.cin_magic);
+    const int ci = kc8 - tap * p.Cin;
+    const int tp = kvalid ? lds_taps[tap] : 0;
+    const int dy = tp >> 16;
+    const int dx = (int)(short)(tp & 0xffff);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int iy = aiy[i] + dy, ix = aix[i] + dx;
+      bool ok = kvalid && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const bf16* src = ok ? abase[i] + ((size_t)(iy * p.IW + ix) * p.Cin + ci) : p.zero;
+      glds16(src, sa + (i * 4 + wid) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const bf16* src = (kvalid && bok[i]) ? bbase[i] + kc8 : p.zero;
+      glds16(src, sb + (i * 4 + wid) * 1024);
+    }
+  };
+
+  // ---- fragment read offsets ----
+  int aoff[MT], aswz[MT], boff[NT], bswz[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int row = wr * WM + mt * 32 + (lane & 31);
+    aoff[mt] = row * ROWB;
+    aswz[mt] = swz_of_row<BK>(row);
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int row = wc * WN + nt * 32 + (lane & 31);
+    boff[nt] = BM * ROWB + row * ROWB;
+    bswz[nt] = swz_of_row<BK>(row);
+  }
+  const int khalf = lane >> 5;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+
+  const int KT = (p.K + BK - 1) / BK;
+  stage(0, 0);
+  wait_vmcnt0();
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
+    const char* base = lds_tiles + cur * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 af[MT], bfr[NT];
+      const int sl = ks * 2 + khalf;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        af[mt] = *(const bf16x8*)(base + aoff[mt] + ((sl ^ aswz[mt]) << 4));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        bfr[nt] = *(const bf16x8*)(base + boff[nt] + ((sl ^ bswz[nt]) << 4));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+    }
+    wait_vmcnt0();
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: bias / relu / bn partial statistics / bf16 rows via LDS ----
+  char* ep = lds_tiles + wid * (WM * EP_PITCH);
+  const int colq = lane & 31;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = n0 + wc * WN + nt * 32 + colq;
+    float bias = 0.f;
+    if (p.bias != nullptr && co < p.Cout) bias = p.bias[co];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float v = acc[mt][nt][j] + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        bf16 hv = (bf16)v;
+        float vr = (float)hv;
+        s1 += vr;
+        s2 += vr * vr;
+        int r = mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * khalf;
+        *(bf16*)(ep + r * EP_PITCH + (nt * 32 + colq) * 2) = hv;
+      }
+    }
+    if (p.stats != nullptr) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (khalf == 0 && co < p.Cout) {
+        size_t prow = (size_t)(tile_m * 2 + wr) * 2;
+        p.stats[prow * p.Cout + co] = s1;
+        p.stats[(prow + 1) * p.Cout + co] = s2;
+      }
+    }
+  }
+  __syncthreads();
+
+  constexpr int CPR = WN / 8;         // 16-byte chunks per row
+  constexpr int RPP = 64 / CPR;       // rows per pass
+#pragma unroll
+  for (int pass = 0; pass < WM / RPP; ++pass) {
+    int r = pass * RPP + lane / CPR;
+    int c = lane % CPR;
+    int m = m0 + wr * WM + r;
+    int co = n0 + wc * WN + c * 8;
+    if (m < p.M && co < p.Cout) {
+      uint4 v = *(const uint4*)(ep + r * EP_PITCH + c * 16);
+      size_t opixel;
+      if (p.dense_out) {
+        opixel = (size_t)m;
+      } else {
+        int b = m / opix;
+        int rem = m - b * opix;
+        int oy = rem / p.OXn;
+        int ox = rem - oy * p.OXn;
+        opixel = ((size_t)b * p.OH + (oy * p.osy + p.oy0)) * p.OW + (ox * p.osx + p.ox0);
+      }
+      *(uint4*)(p.y + opixel * p.Cout + co) = v;
+    }
+  }
+}
+
+template <int BM, int BN, int BK>
+static int launch_conv(const ConvArgs& a, hipStream_t stream) {
+  constexpr int ROWB = BK * 2;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int EP = 4 * (BM / 2) * ((BN / 2) * 2 + 16);
+  size_t lds = MAX_TAPS * 4 + (size_t)((2 * STAGE > EP) ? 2 * STAGE : EP);
+  unsigned mtiles = (a.M + BM - 1) / BM, ntiles = (a.Cout + BN - 1) / BN;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK>), dim3(mtiles * ntiles), dim3(256), lds, stream, a);
+  return (int)hipGetLastError();
+}
+
+// Number of partial-statistics rows the kernel writes for a given M and BM.
+extern "C" int dtfa_conv_stats_rows(int M, int bm) { return ((M + bm - 1) / bm) * 2; }
+
+extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, hipStream_t stream) {
+  if (a->Cin % 8 != 0 || a->Cout % 8 != 0 || a->T > MAX_TAPS || a->T < 1) return -1;
+  if (a->K != a->T * a->Cin || a->K >= (1 << 16)) return -2;
+  if (a->M <= 0) return 0;
+#define CASE(BM_, BN_, BK_) \
+  if (bm == BM_ && bn == BN_ && bk == BK_) return launch_conv<BM_, BN_, BK_>(*a, stream);
+  CASE(128, 128, 32)
+  CASE(128, 64, 32)
+  CASE(64, 64, 32)
+  CASE(256, 128, 32)
+  CASE(128, 128, 64)
+  CASE(128, 64, 64)
+  CASE(64, 64, 64)
+  CASE(256, 128, 64)
+#undef CASE
+  return -3;
+}

@@ -1,0 +1,289 @@
+// Weight-gradient of the tap-table convolution for gfx950 (MI355X).
+//
+//   dW[co][tap][ci] = sum_m dY[m][co] * X[pixel(m) + tap][ci]
+//
+// GEMM view: rows = cout, cols = (tap, cin), reduction = output pixels m.
+// Both operands are stored pixel-major (NHWC), i.e. the reduction index is the
+// *slow* memory axis, so the MFMA fragments (8 consecutive k per lane) are
+// fetched from the LDS tiles with the gfx950 transposing read
+// ds_read_b64_tr_b16.  Tiles are staged with LDS-DMA (global_load_lds_dwordx4);
+// the im2col gather and the zero padding live in the per-lane source address,
+// and the bank swizzle is applied through the source chunk choice.
+//
+// The reduction is split across blockIdx.y; every split writes an fp32 slab
+// [split][Cout][K] and a second kernel sums the slabs in a fixed order, so the
+// result is bitwise reproducible.
+#include "common.h"
+
+struct WgradArgs {
+  const bf16* x;     // [B, IH, IW, Cin]
+  const bf16* dy;    // [B, OH, OW, Cout] dense, M = B*OH*OW rows
+  float* slab;       // [splits][Cout][K]
+  const bf16* zero;
+  const int* taps;   // (dy << 16) | (dx & 0xffff)
+  int IH, IW, Cin;
+  int OH, OW, Cout;
+  int isy, isx;
+  int T, M, K;
+  unsigned cin_magic;
+  int ktiles_per_split;
+  // decomposition of one k-tile step (BKP pixels) into (images, rows, cols)
+  int step_b, step_y, step_x;
+};
+
+#define MAX_TAPS 64
+
+template <int RB>
+__device__ __forceinline__ int wswz(int row) {
+  constexpr int RBR = 256 / RB;  // rows per 256-byte bank row
+  return ((row / RBR) & (4 / RBR - 1)) << 2;
+}
+
+__device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)p);
+}
+
+template <int BMW, int BNW, int BKP>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+  constexpr int RBA = BMW * 2, RBB = BNW * 2;       // row bytes
+  constexpr int CPRA = RBA / 16, CPRB = RBB / 16;   // 16-byte chunks per row
+  constexpr int RPIA = 64 / CPRA, RPIB = 64 / CPRB; // rows per wave-instruction
+  constexpr int NA = BKP / (4 * RPIA), NB = BKP / (4 * RPIB);
+  constexpr int WM = BMW / 2, WN = BNW / 2;
+  constexpr int MT = WM / 32, NT = WN / 32;
+  constexpr int KS = BKP / 16;
+  constexpr int STAGE = BKP * (RBA + RBB);
+  static_assert(NA >= 1 && NB >= 1, "tile too small");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* lds_taps = (int*)smem;
+  char* lds_tiles = smem + MAX_TAPS * 4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+
+  const unsigned ntiles = (p.K + BNW - 1) / BNW;
+  const unsigned tile_m = blockIdx.x / ntiles, tile_n = blockIdx.x % ntiles;
+  const int co0 = tile_m * BMW, n0 = tile_n * BNW;
+  const int split = blockIdx.y;
+
+  if (tid < p.T) lds_taps[tid] = p.taps[tid];
+  __syncthreads();
+
+  const int kt_begin = split * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  const int kt_total = (p.M + BKP - 1) / BKP;
+  if (kt_end > kt_total) kt_end = kt_total;
+
+  // ---- A' (dY) staging rows ----
+  const int a_row = lane / CPRA;                                 // row within instruction
+  const int a_chunk = (lane % CPRA) ^ wswz<RBA>(a_row);          // logical chunk (RPIA % 4 == 0)
+  const int a_co = co0 + a_chunk * 8;
+  const bool a_ok = a_co < p.Cout;
+
+  // ---- B' (X gather) staging rows ----
+  const int b_row = lane / CPRB;
+  const int b_chunk = (lane % CPRB) ^ wswz<RBB>(b_row);
+  const int b_n = n0 + b_chunk * 8;
+  const bool b_kok = b_n < p.K;
+  int b_tap = (int)__umulhi((unsigned)b_n, p.cin_magic);
+  const int b_ci = b_n - b_tap * p.Cin;
+  const int tp = b_kok ? lds_taps[b_tap] : 0;
+  const int b_dy = tp >> 16, b_dx = (int)(short)(tp & 0xffff);
+
+  const int opix = p.OH * p.OW;
+  int boy[NB], box[NB], bpix[NB], bm[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    int m = kt_begin * BKP + (i * 4 + wid) * RPIB + b_row;
+    bm[i] = m;
+    int b = m / opix;
+    int rem = m - b * opix;
+    boy[i] = rem / p.OW;
+    box[i] = rem - boy[i] * p.OW;
+    bpix[i] = b * p.IH * p.IW;
+  }
+  const int img_pix = p.IH * p.IW;
+
+  auto stage = [&](int kt, int buf) {
+    char* sa = lds_tiles + buf * STAGE;
+    char* sb = sa + BKP * RBA;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int m = kt * BKP + (i * 4 + wid) * RPIA + a_row;
+      const bf16* src = (a_ok && m < p.M) ? p.dy + (size_t)m * p.Cout + a_co : p.zero;
+      glds16(src, sa + (i * 4 + wid) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int iy = boy[i] * p.isy + b_dy, ix = box[i] * p.isx + b_dx;
+      bool ok = b_kok && bm[i] < p.M && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const bf16* src = ok ? p.x + ((size_t)(bpix[i] + iy * p.IW + ix) * p.Cin + b_ci) : p.zero;
+      glds16(src, sb + (i * 4 + wid) * 1024);
+      // advance this row by one k-tile (BKP pixels)
+      bm[i] += BKP;
+      box[i] += p.step_x;
+      if (box[i] >= p.OW) { box[i] -= p.OW; boy[i] += 1; }
+      boy[i] += p.step_y;
+      if (boy[i] >= p.OH) { boy[i] -= p.OH; bpix[i] += img_pix; }
+      bpix[i] += p.step_b * img_pix;
+    }
+  };
+
+  // ---- transposed fragment read offsets ----
+  // lane -> (k row within 16-step, column) of the 4x16 block it addresses
+  const int tr_q = (lane & 15) >> 2;            // block row supplied by this lane
+  const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int tr_k = 8 * (lane >> 5) + tr_q;      // + 4*r for the second read, + 16*ks
+  int acol[MT], bcol[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acol[mt] = wr * WM + mt * 32 + tr_col;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bcol[nt] = wc * WN + nt * 32 + tr_col;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+
+  if (kt_begin < kt_end) {
+    stage(kt_begin, 0);
+    wait_vmcnt0();
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
+      const char* sa = lds_tiles + cur * STAGE;
+      const char* sb = sa + BKP * RBA;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s16x8 af[MT], bfr[NT];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int krow = ks * 16 + tr_k + 4 * r;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            int ch = (acol[mt] >> 3) ^ wswz<RBA>(krow);
+            s16x4 v = lds_tr_read(sa + krow * RBA + ch * 16 + (acol[mt] & 7) * 2);
+            af[mt][4 * r + 0] = v[0]; af[mt][4 * r + 1] = v[1];
+            af[mt][4 * r + 2] = v[2]; af[mt][4 * r + 3] = v[3];
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            int ch = (bcol[nt] >> 3) ^ wswz<RBB>(krow);
+            s16x4 v = lds_tr_read(sb + krow * RBB + ch * 16 + (bcol[nt] & 7) * 2);
+            bfr[nt][4 * r + 0] = v[0]; bfr[nt][4 * r + 1] = v[1];
+            bfr[nt][4 * r + 2] = v[2]; bfr[nt][4 * r + 3] = v[3];
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, af[mt]), __builtin_bit_cast(bf16x8, bfr[nt]), acc[mt][nt], 0, 0, 0);
+      }
+      wait_vmcnt0();
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // ---- store the fp32 partial tile ----
+  float* slab = p.slab + (size_t)split * p.Cout * p.K;
+  const int colq = lane & 31, khalf = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      int n = n0 + wc * WN + nt * 32 + colq;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        int co = co0 + wr * WM + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * khalf;
+        if (co < p.Cout && n < p.K) slab[(size_t)co * p.K + n] = acc[mt][nt][j];
+      }
+    }
+}
+
+// Sum the split slabs in split order; write (or accumulate into) the gradient.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, size_t n,
+                                    float* __restrict__ out_f32, bf16* __restrict__ out_bf16,
+                                    int accumulate) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    float4 s = *(const float4*)(slab + i);
+    for (int k = 1; k < splits; ++k) {
+      float4 v = *(const float4*)(slab + (size_t)k * n + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (out_f32) {
+      if (accumulate) {
+        float4 o = *(float4*)(out_f32 + i);
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+      }
+      *(float4*)(out_f32 + i) = s;
+    }
+    if (out_bf16) {
+      out_bf16[i] = (bf16)s.x; out_bf16[i + 1] = (bf16)s.y;
+      out_bf16[i + 2] = (bf16)s.z; out_bf16[i + 3] = (bf16)s.w;
+    }
+  } else {
+    for (; i < n; ++i) {
+      float s = 0.f;
+      for (int k = 0; k < splits; ++k) s += slab[(size_t)k * n + i];
+      if (out_f32) out_f32[i] = accumulate ? out_f32[i] + s : s;
+      if (out_bf16) out_bf16[i] = (bf16)s;
+    }
+  }
+}
+
+template <int BMW, int BNW, int BKP>
+static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t stream) {
+  size_t lds = MAX_TAPS * 4 + 2 * (size_t)BKP * (BMW * 2 + BNW * 2);
+  unsigned mt = (a.Cout + BMW - 1) / BMW, nt = (a.K + BNW - 1) / BNW;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, BKP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, BKP>), dim3(mt * nt, splits), dim3(256), lds, stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dtfa_conv_wgrad(WgradArgs* a, int bmw, int bnw, int bkp, int splits, hipStream_t stream) {
+  if (a->Cin % 8 != 0 || a->Cout % 8 != 0 || a->T > MAX_TAPS || a->T < 1) return -1;
+  if (a->K != a->T * a->Cin || a->K >= (1 << 16) || splits < 1) return -2;
+  int kt_total = (a->M + bkp - 1) / bkp;
+  a->ktiles_per_split = (kt_total + splits - 1) / splits;
+  int opix = a->OH * a->OW;
+  a->step_b = bkp / opix;
+  int rem = bkp % opix;
+  a->step_y = rem / a->OW;
+  a->step_x = rem % a->OW;
+#define CASE(A_, B_, C_) \
+  if (bmw == A_ && bnw == B_ && bkp == C_) return launch_wgrad<A_, B_, C_>(*a, splits, stream);
+  CASE(128, 128, 32)
+  CASE(64, 128, 32)
+  CASE(128, 64, 32)
+  CASE(64, 64, 32)
+  CASE(128, 128, 64)
+  CASE(64, 128, 64)
+#undef CASE
+  return -3;
+}
+
+extern "C" int dtfa_wgrad_reduce(const float* slab, int splits, long long n, float* out_f32, void* out_bf16,
+                                 int accumulate, hipStream_t stream) {
+  if (n <= 0) return 0;
+  size_t threads = ((size_t)n + 3) / 4;
+  unsigned blocks = (unsigned)((threads + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, splits, (size_t)n, out_f32,
+                     (bf16*)out_bf16, accumulate);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,84 @@
+// Small support kernels (gfx950): weight-matrix permutation for the
+// data-gradient convolution, counter-based dropout, fills.
+#include "common.h"
+
+// ----------------------------------------------------------------------------
+// dst[ci][j][co] = src[co][src_tap[j]][ci]      (bf16)
+// src is the forward weight matrix [Cout][T][Cin]; dst is the weight matrix of
+// the data-gradient convolution restricted to the taps listed in src_tap
+// (TP entries).  32x32 tiles of the (co, ci) plane are transposed through LDS so
+// both the read and the write are contiguous.
+// ----------------------------------------------------------------------------
+__global__ void weight_permute_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
+                                      const int* __restrict__ src_tap, int Cout, int T, int Cin, int TP) {
+  __shared__ bf16 tile[32][33];
+  const int j = blockIdx.z;
+  const int t = src_tap[j];
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < Cout && ci < Cin) ? src[((size_t)co * T + t) * Cin + ci] : (bf16)0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int ci = ci0 + r, co = co0 + tx;
+    if (ci < Cin && co < Cout) dst[((size_t)ci * TP + j) * Cout + co] = tile[tx][r];
+  }
+}
+
+extern "C" int dtfa_weight_permute(const void* src, void* dst, const int* src_tap, int Cout, int T, int Cin, int TP,
+                                   hipStream_t st) {
+  if (TP <= 0) return 0;
+  dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, TP);
+  hipLaunchKernelGGL(weight_permute_kernel, grid, dim3(256), 0, st, (const bf16*)src, (bf16*)dst, src_tap, Cout, T,
+                     Cin, TP);
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
+// Dropout.  The keep decision for element i is a pure function of
+// (seed, i), so the backward pass regenerates the identical mask instead of
+// storing it:  y = keep(i) ? x * scale : 0.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+__global__ void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t n, unsigned seed_lo,
+                               unsigned seed_hi, unsigned thresh16, float scale) {
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n;
+       i += (size_t)gridDim.x * blockDim.x * 2) {
+    unsigned h = mix32((unsigned)(i >> 1) * 0x9e3779b9u + seed_lo);
+    h = mix32(h ^ seed_hi ^ (unsigned)(i >> 33));
+    unsigned r0 = h & 0xffff, r1 = h >> 16;
+    float a = (float)x[i];
+    y[i] = (bf16)(r0 >= thresh16 ? a * scale : 0.f);
+    if (i + 1 < n) {
+      float b = (float)x[i + 1];
+      y[i + 1] = (bf16)(r1 >= thresh16 ? b * scale : 0.f);
+    }
+  }
+}
+
+// rate = drop probability; the same call with dy as input is the backward.
+extern "C" int dtfa_dropout(const void* x, void* y, long long n, unsigned long long seed, float rate,
+                            hipStream_t st) {
+  if (n <= 0) return 0;
+  if (!(rate >= 0.f) || rate >= 1.f) return -1;
+  unsigned thresh = (unsigned)(rate * 65536.f + 0.5f);
+  float scale = 1.f / (1.f - (float)thresh / 65536.f);
+  size_t pairs = ((size_t)n + 1) / 2;
+  size_t blocks = (pairs + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)y, (size_t)n,
+                     (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), thresh, scale);
+  return (int)hipGetLastError();
+}
+
+// Library self-description, used by the Python loader to verify the build.
+extern "C" const char* dtfa_hip_arch() { return "gfx950"; }
+extern "C" int dtfa_hip_abi_version() { return 1; }

@@ -1,0 +1,310 @@
+"""Convolution on the gfx950 implicit-GEMM kernels.
+
+A :class:`ConvPlan` captures the geometry of one convolution layer at one input
+size and owns the small device tables the kernels need (tap offsets, the tap
+subsets of every data-gradient phase).  The three entry points map onto the two
+kernels in ``csrc/hip``:
+
+* :func:`conv_fwd`    -- ``conv_igemm`` with the forward tap table
+* :func:`conv_dgrad`  -- ``conv_igemm`` run on ``dY`` with permuted weights, one
+  launch per output-stride phase so no multiply is wasted on the zeros a
+  strided convolution's transpose would insert
+* :func:`conv_wgrad`  -- ``conv_wgrad`` (split over pixels) + slab reduction
+
+TensorFlow padding rules ("SAME" puts the odd pixel at the bottom/right) are
+honoured through explicit ``(top, bottom, left, right)`` pads.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import hipk
+
+
+def same_pads(size: int, k: int, s: int) -> Tuple[int, int]:
+    """TensorFlow SAME padding for one axis -> (before, after)."""
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return total // 2, total - total // 2
+
+
+def out_size(size: int, k: int, s: int, p0: int, p1: int) -> int:
+    return (size + p0 + p1 - k) // s + 1
+
+
+def resolve_pads(padding, ih: int, iw: int, kh: int, kw: int, sy: int, sx: int) -> Tuple[int, int, int, int]:
+    """padding: 'SAME' | 'VALID' | int | (ph, pw) | (top, bottom, left, right)."""
+    if isinstance(padding, str):
+        p = padding.upper()
+        if p == "VALID":
+            return (0, 0, 0, 0)
+        if p == "SAME":
+            t, b = same_pads(ih, kh, sy)
+            l, r = same_pads(iw, kw, sx)
+            return (t, b, l, r)
+        raise ValueError("unknown padding %r" % padding)
+    if isinstance(padding, int):
+        return (padding, padding, padding, padding)
+    if len(padding) == 2:
+        return (padding[0], padding[0], padding[1], padding[1])
+    return tuple(padding)  # type: ignore[return-value]
+
+
+def _pack_taps(taps: List[Tuple[int, int]]) -> List[int]:
+    out = []
+    for dy, dx in taps:
+        if not (-32768 <= dy < 32768 and -32768 <= dx < 32768):
+            raise ValueError("tap offset out of int16 range")
+        v = ((dy & 0xFFFF) << 16) | (dx & 0xFFFF)
+        if v >= 1 << 31:
+            v -= 1 << 32
+        out.append(v)
+    return out
+
+
+def _magic(d: int) -> int:
+    return ((1 << 32) + d - 1) // d if d > 1 else 0xFFFFFFFF
+
+
+@dataclass
+class _Phase:
+    taps: torch.Tensor      # packed (dy, dx) offsets into dY
+    src_tap: torch.Tensor   # forward tap index of every phase tap
+    T: int
+    OYn: int
+    OXn: int
+    oy0: int
+    ox0: int
+
+
+class ConvPlan:
+    """Geometry + device tables of one convolution at one spatial size."""
+
+    def __init__(self, ih, iw, cin, cout, kh, kw, sy, sx, pads, device):
+        if cin % 8 or cout % 8:
+            raise ValueError("conv kernels need Cin %% 8 == 0 and Cout %% 8 == 0 (got %d, %d)" % (cin, cout))
+        if kh * kw > 64:
+            raise ValueError("at most 64 taps supported")
+        if kh * kw * cin >= 1 << 16:
+            raise ValueError("K = kh*kw*Cin must be < 65536")
+        self.ih, self.iw, self.cin, self.cout = ih, iw, cin, cout
+        self.kh, self.kw, self.sy, self.sx = kh, kw, sy, sx
+        self.pads = tuple(pads)
+        pt, pb, pl, pr = self.pads
+        self.oh = out_size(ih, kh, sy, pt, pb)
+        self.ow = out_size(iw, kw, sx, pl, pr)
+        if self.oh <= 0 or self.ow <= 0:
+            raise ValueError("empty convolution output")
+        self.T = kh * kw
+        self.K = self.T * cin
+        self.device = torch.device(device)
+        fwd = [(ky - pt, kx - pl) for ky in range(kh) for kx in range(kw)]
+        self.fwd_taps = torch.tensor(_pack_taps(fwd), dtype=torch.int32, device=device)
+        # data-gradient phases
+        self.phases: List[_Phase] = []
+        self.dgrad_needs_zero = False
+        for ph in range(sy):
+            for pw in range(sx):
+                oyn = (ih - ph + sy - 1) // sy if ih > ph else 0
+                oxn = (iw - pw + sx - 1) // sx if iw > pw else 0
+                if oyn <= 0 or oxn <= 0:
+                    continue
+                taps, src = [], []
+                for ky in range(kh):
+                    if (ph + pt - ky) % sy:
+                        continue
+                    for kx in range(kw):
+                        if (pw + pl - kx) % sx:
+                            continue
+                        taps.append(((ph + pt - ky) // sy, (pw + pl - kx) // sx))
+                        src.append(ky * kw + kx)
+                if not taps:
+                    self.dgrad_needs_zero = True
+                    continue
+                self.phases.append(_Phase(
+                    torch.tensor(_pack_taps(taps), dtype=torch.int32, device=device),
+                    torch.tensor(src, dtype=torch.int32, device=device),
+                    len(taps), oyn, oxn, ph, pw))
+        self.cin_magic = _magic(cin)
+        self.cout_magic = _magic(cout)
+
+
+_plans: Dict[tuple, ConvPlan] = {}
+
+
+def get_plan(ih, iw, cin, cout, kh, kw, sy, sx, pads, device) -> ConvPlan:
+    key = (ih, iw, cin, cout, kh, kw, sy, sx, tuple(pads), str(device))
+    p = _plans.get(key)
+    if p is None:
+        p = ConvPlan(ih, iw, cin, cout, kh, kw, sy, sx, pads, device)
+        _plans[key] = p
+    return p
+
+
+# --------------------------------------------------------------------------
+# tile selection
+# --------------------------------------------------------------------------
+_FWD_TILES = {(128, 128), (128, 64), (64, 64), (256, 128)}
+
+
+def _env_tile(name: str):
+    v = os.environ.get(name)
+    if not v:
+        return None
+    return tuple(int(t) for t in v.split(","))
+
+
+def pick_fwd_tile(M: int, cout: int, K: int) -> Tuple[int, int, int]:
+    forced = _env_tile("DTFA_CONV_TILE")
+    if forced:
+        return forced  # type: ignore[return-value]
+    bk = 64 if K % 64 == 0 and K >= 256 else 32
+    bn = 128 if cout > 64 else 64
+    bm = 128
+    tiles = -(-M // bm) * -(-cout // bn)
+    if bn == 64 and tiles < 512:
+        bm = 64
+    elif bn == 128 and tiles >= 2048 and cout % 128 == 0:
+        bm = 256
+    return bm, bn, bk
+
+
+def pick_wgrad_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
+    forced = _env_tile("DTFA_WGRAD_TILE")
+    bmw = 128 if cout > 64 else 64
+    bnw = 128 if K > 64 else 64
+    bkp = 32
+    if forced:
+        bmw, bnw, bkp = forced[:3]
+    tiles = -(-cout // bmw) * -(-K // bnw)
+    kt_total = -(-M // bkp)
+    splits = max(1, min(-(-1024 // tiles), max(1, kt_total // 8), 1024))
+    if forced and len(forced) > 3:
+        splits = forced[3]
+    return bmw, bnw, bkp, splits
+
+
+# --------------------------------------------------------------------------
+# launches
+# --------------------------------------------------------------------------
+def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, osx, oy0, ox0, isy, isx, B,
+                  cin_magic, bias=None, relu=False, stats=False):
+    M = B * oyn * oxn
+    K = T * cin
+    bm, bn, bk = pick_fwd_tile(M, cout, K)
+    L = hipk.lib()
+    part = None
+    if stats:
+        rows = L.dtfa_conv_stats_rows(M, bm)
+        part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+    a = hipk.ConvArgs()
+    a.x, a.w, a.y = x.data_ptr(), w2d.data_ptr(), y.data_ptr()
+    a.bias = hipk.ptr(bias)
+    a.stats = hipk.ptr(part)
+    a.zero = hipk.zero_page(x.device).data_ptr()
+    a.taps = taps.data_ptr()
+    a.IH, a.IW, a.Cin = ih, iw, cin
+    a.OH, a.OW, a.Cout = oh, ow, cout
+    a.OYn, a.OXn = oyn, oxn
+    a.osy, a.osx, a.oy0, a.ox0 = osy, osx, oy0, ox0
+    a.isy, a.isx = isy, isx
+    a.T, a.M, a.K = T, M, K
+    a.cin_magic = cin_magic
+    a.relu = 1 if relu else 0
+    a.dense_out = 1 if (osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow) else 0
+    hipk.check(L.dtfa_conv_igemm(C.byref(a), bm, bn, bk, hipk.stream()), "conv_igemm %dx%dx%d" % (bm, bn, bk))
+    return part
+
+
+def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[torch.Tensor] = None,
+             relu: bool = False, want_stats: bool = False):
+    """x [B,IH,IW,Cin] bf16, w [Cout,KH,KW,Cin] bf16 -> (y [B,OH,OW,Cout] bf16, stats partials or None)."""
+    hipk.require(x, torch.bfloat16, "x")
+    hipk.require(w, torch.bfloat16, "w")
+    B = x.shape[0]
+    if tuple(x.shape[1:]) != (plan.ih, plan.iw, plan.cin):
+        raise ValueError("input shape %s does not match plan (%d,%d,%d)" % (tuple(x.shape), plan.ih, plan.iw, plan.cin))
+    if w.numel() != plan.cout * plan.K or w.shape[0] != plan.cout:
+        raise ValueError("weight shape %s does not match plan" % (tuple(w.shape),))
+    if bias is not None:
+        hipk.require(bias, torch.float32, "bias")
+        if bias.numel() != plan.cout:
+            raise ValueError("bias size")
+        if want_stats:
+            raise ValueError("batch-norm statistics and bias are mutually exclusive")
+    if B * plan.oh * plan.ow >= 1 << 31:
+        raise ValueError("too many output pixels for 32-bit row indices")
+    y = torch.empty((B, plan.oh, plan.ow, plan.cout), dtype=torch.bfloat16, device=x.device)
+    part = _launch_igemm(x, w, y, plan.fwd_taps, plan.T, plan.ih, plan.iw, plan.cin, plan.oh, plan.ow, plan.cout,
+                         plan.oh, plan.ow, 1, 1, 0, 0, plan.sy, plan.sx, B, plan.cin_magic, bias, relu, want_stats)
+    return y, part
+
+
+def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan) -> torch.Tensor:
+    """dy [B,OH,OW,Cout] -> dx [B,IH,IW,Cin]."""
+    hipk.require(dy, torch.bfloat16, "dy")
+    hipk.require(w, torch.bfloat16, "w")
+    B = dy.shape[0]
+    if tuple(dy.shape[1:]) != (plan.oh, plan.ow, plan.cout):
+        raise ValueError("dy shape %s does not match plan" % (tuple(dy.shape),))
+    if w.numel() != plan.cout * plan.K:
+        raise ValueError("weight shape does not match plan")
+    L = hipk.lib()
+    if plan.dgrad_needs_zero:
+        dx = torch.zeros((B, plan.ih, plan.iw, plan.cin), dtype=torch.bfloat16, device=dy.device)
+    else:
+        dx = torch.empty((B, plan.ih, plan.iw, plan.cin), dtype=torch.bfloat16, device=dy.device)
+    for ph in plan.phases:
+        wd = torch.empty((plan.cin, ph.T * plan.cout), dtype=torch.bfloat16, device=dy.device)
+        hipk.check(L.dtfa_weight_permute(w.data_ptr(), wd.data_ptr(), ph.src_tap.data_ptr(), plan.cout, plan.T,
+                                         plan.cin, ph.T, hipk.stream()), "weight_permute")
+        _launch_igemm(dy, wd, dx, ph.taps, ph.T, plan.oh, plan.ow, plan.cout, plan.ih, plan.iw, plan.cin,
+                      ph.OYn, ph.OXn, plan.sy, plan.sx, ph.oy0, ph.ox0, 1, 1, B, plan.cout_magic)
+    return dx
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[torch.Tensor] = None,
+               accumulate: bool = False) -> torch.Tensor:
+    """Weight gradient [Cout,KH,KW,Cin].  ``out`` may be an fp32 or bf16 buffer
+    of the right size (written, or added to when ``accumulate``); by default a
+    new fp32 tensor is returned."""
+    hipk.require(x, torch.bfloat16, "x")
+    hipk.require(dy, torch.bfloat16, "dy")
+    B = x.shape[0]
+    if tuple(x.shape[1:]) != (plan.ih, plan.iw, plan.cin) or tuple(dy.shape) != (B, plan.oh, plan.ow, plan.cout):
+        raise ValueError("wgrad operand shapes do not match plan")
+    M = B * plan.oh * plan.ow
+    if M >= 1 << 31 or B * plan.ih * plan.iw >= 1 << 31:
+        raise ValueError("too many pixels for 32-bit indices")
+    bmw, bnw, bkp, splits = pick_wgrad_tile(M, plan.cout, plan.K)
+    n = plan.cout * plan.K
+    slab = hipk.workspace(x.device, splits * n * 4)
+    if out is None:
+        out = torch.empty((plan.cout, plan.kh, plan.kw, plan.cin), dtype=torch.float32, device=x.device)
+        accumulate = False
+    if out.numel() != n or not out.is_contiguous() or out.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("bad wgrad output buffer")
+    if out.dtype == torch.bfloat16 and accumulate:
+        raise ValueError("accumulation needs an fp32 gradient buffer")
+    L = hipk.lib()
+    a = hipk.WgradArgs()
+    a.x, a.dy, a.slab = x.data_ptr(), dy.data_ptr(), slab.data_ptr()
+    a.zero = hipk.zero_page(x.device).data_ptr()
+    a.taps = plan.fwd_taps.data_ptr()
+    a.IH, a.IW, a.Cin = plan.ih, plan.iw, plan.cin
+    a.OH, a.OW, a.Cout = plan.oh, plan.ow, plan.cout
+    a.isy, a.isx = plan.sy, plan.sx
+    a.T, a.M, a.K = plan.T, M, plan.K
+    a.cin_magic = plan.cin_magic
+    hipk.check(L.dtfa_conv_wgrad(C.byref(a), bmw, bnw, bkp, splits, hipk.stream()), "conv_wgrad")
+    f32 = out.data_ptr() if out.dtype == torch.float32 else None
+    b16 = out.data_ptr() if out.dtype == torch.bfloat16 else None
+    hipk.check(L.dtfa_wgrad_reduce(slab.data_ptr(), splits, n, f32, b16, 1 if accumulate else 0, hipk.stream()),
+               "wgrad_reduce")
+    return out

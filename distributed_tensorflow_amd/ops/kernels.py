@@ -1,0 +1,309 @@
+"""Host-side launch helpers for the non-convolution HIP kernels.
+
+Each helper validates operands, allocates outputs through the torch caching
+allocator (so the launches are stream-ordered and hipGraph-capturable) and
+launches on the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import hipk
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _as2d(t: torch.Tensor) -> Tuple[int, int]:
+    c = t.shape[-1]
+    return t.numel() // c, c
+
+
+# ------------------------------------------------------------------ batch norm
+def reduce_partials(part: torch.Tensor, max_rows: int = 128) -> torch.Tensor:
+    """[R][NV][C] -> [RS<=max_rows][NV][C] (fixed summation order)."""
+    R, NV, Cc = part.shape
+    if R <= max_rows:
+        return part
+    out = torch.empty((max_rows, NV, Cc), dtype=F32, device=part.device)
+    hipk.check(hipk.lib().dtfa_partial_reduce(part.data_ptr(), out.data_ptr(), R, NV, Cc, max_rows, hipk.stream()),
+               "partial_reduce")
+    return out
+
+
+def bn_stats_partials(x: torch.Tensor) -> torch.Tensor:
+    hipk.require(x, BF16, "x")
+    M, Cc = _as2d(x)
+    L = hipk.lib()
+    rows = L.dtfa_col_partials_rows(M, Cc)
+    part = torch.empty((rows, 2, Cc), dtype=F32, device=x.device)
+    hipk.check(L.dtfa_bn_stats_partials(x.data_ptr(), part.data_ptr(), M, Cc, hipk.stream()), "bn_stats_partials")
+    return part
+
+
+def bn_finalize(part: torch.Tensor, count: int, eps: float, gamma, beta, run_mean, run_var, momentum: float):
+    part = reduce_partials(part)
+    R, _, Cc = part.shape
+    dev = part.device
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (run_mean, "running_mean"), (run_var, "running_var")):
+        if t is not None:
+            hipk.require(t, F32, nm)
+            if t.numel() != Cc:
+                raise ValueError("%s has %d elements, expected %d" % (nm, t.numel(), Cc))
+    out = torch.empty((4, Cc), dtype=F32, device=dev)
+    mean, invstd, scale, shift = out[0], out[1], out[2], out[3]
+    hipk.check(hipk.lib().dtfa_bn_finalize(part.data_ptr(), R, Cc, float(count), float(eps), hipk.ptr(gamma),
+                                           hipk.ptr(beta), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                                           shift.data_ptr(), hipk.ptr(run_mean), hipk.ptr(run_var), float(momentum),
+                                           hipk.stream()), "bn_finalize")
+    return mean, invstd, scale, shift
+
+
+def bn_eval_coeffs(gamma, beta, run_mean, run_var, eps: float):
+    hipk.require(run_mean, F32, "running_mean")
+    hipk.require(run_var, F32, "running_var")
+    Cc = run_mean.numel()
+    out = torch.empty((2, Cc), dtype=F32, device=run_mean.device)
+    hipk.check(hipk.lib().dtfa_bn_eval_coeffs(Cc, float(eps), hipk.ptr(gamma), hipk.ptr(beta), run_mean.data_ptr(),
+                                              run_var.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                              hipk.stream()), "bn_eval_coeffs")
+    return out[0], out[1]
+
+
+def bn_apply(y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool,
+             residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    hipk.require(y, BF16, "y")
+    M, Cc = _as2d(y)
+    if scale.numel() != Cc or shift.numel() != Cc:
+        raise ValueError("scale/shift size mismatch")
+    if residual is not None:
+        hipk.require(residual, BF16, "residual")
+        if residual.shape != y.shape:
+            raise ValueError("residual shape mismatch")
+    z = torch.empty_like(y)
+    hipk.check(hipk.lib().dtfa_bn_apply(y.data_ptr(), hipk.ptr(residual), z.data_ptr(), scale.data_ptr(),
+                                        shift.data_ptr(), M, Cc, 1 if relu else 0, hipk.stream()), "bn_apply")
+    return z
+
+
+def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, dgamma_out=None, dbeta_out=None,
+                accumulate=False):
+    """Returns (dy, dres or None, dgamma, dbeta).  ``zout`` (the activation
+    output) is only read when ``relu``."""
+    hipk.require(dz, BF16, "dz")
+    hipk.require(y, BF16, "y")
+    if dz.shape != y.shape:
+        raise ValueError("dz/y shape mismatch")
+    if relu:
+        hipk.require(zout, BF16, "zout")
+        if zout.shape != y.shape:
+            raise ValueError("zout shape mismatch")
+    M, Cc = _as2d(y)
+    L = hipk.lib()
+    rows = L.dtfa_col_partials_rows(M, Cc)
+    part = torch.empty((rows, 2, Cc), dtype=F32, device=y.device)
+    hipk.check(L.dtfa_bn_bwd_partials(dz.data_ptr(), y.data_ptr(), hipk.ptr(zout) if relu else None,
+                                      mean.data_ptr(), invstd.data_ptr(), part.data_ptr(), M, Cc,
+                                      1 if relu else 0, hipk.stream()), "bn_bwd_partials")
+    part = reduce_partials(part)
+    coef = torch.empty((3, Cc), dtype=F32, device=y.device)
+    dgamma = dgamma_out if dgamma_out is not None else torch.empty(Cc, dtype=F32, device=y.device)
+    dbeta = dbeta_out if dbeta_out is not None else torch.empty(Cc, dtype=F32, device=y.device)
+    acc = 1 if (accumulate and dgamma_out is not None) else 0
+    hipk.check(L.dtfa_bn_bwd_finalize(part.data_ptr(), part.shape[0], Cc, float(M), hipk.ptr(gamma),
+                                      mean.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                      coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), acc,
+                                      hipk.stream()), "bn_bwd_finalize")
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_dres else None
+    hipk.check(L.dtfa_bn_bwd_apply(dz.data_ptr(), y.data_ptr(), hipk.ptr(zout) if relu else None, dy.data_ptr(),
+                                   hipk.ptr(dres), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), M, Cc,
+                                   1 if relu else 0, hipk.stream()), "bn_bwd_apply")
+    return dy, dres, dgamma, dbeta
+
+
+def relu_bwd(dz: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    hipk.require(dz, BF16, "dz")
+    hipk.require(z, BF16, "z")
+    if dz.numel() != z.numel() or dz.numel() % 8:
+        raise ValueError("relu_bwd size")
+    dx = torch.empty_like(dz)
+    hipk.check(hipk.lib().dtfa_relu_bwd(dz.data_ptr(), z.data_ptr(), dx.data_ptr(), dz.numel(), hipk.stream()),
+               "relu_bwd")
+    return dx
+
+
+def add_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    hipk.require(a, BF16, "a")
+    hipk.require(b, BF16, "b")
+    if a.shape != b.shape or a.numel() % 8:
+        raise ValueError("add_bf16 size")
+    o = torch.empty_like(a)
+    hipk.check(hipk.lib().dtfa_add_bf16(a.data_ptr(), b.data_ptr(), o.data_ptr(), a.numel(), hipk.stream()), "add")
+    return o
+
+
+# ------------------------------------------------------------------ pooling
+def _pool_args(x_shape, k, stride, pads, oh, ow, include_pad=False) -> hipk.PoolArgs:
+    B, IH, IW, Cc = x_shape
+    p = hipk.PoolArgs()
+    p.B, p.IH, p.IW, p.C, p.OH, p.OW = B, IH, IW, Cc, oh, ow
+    p.kh, p.kw, p.sy, p.sx = k[0], k[1], stride[0], stride[1]
+    p.pt, p.pl = pads[0], pads[2]
+    p.count_include_pad = 1 if include_pad else 0
+    return p
+
+
+def pool_out_shape(x_shape, k, stride, pads):
+    B, IH, IW, Cc = x_shape
+    oh = (IH + pads[0] + pads[1] - k[0]) // stride[0] + 1
+    ow = (IW + pads[2] + pads[3] - k[1]) // stride[1] + 1
+    if oh <= 0 or ow <= 0:
+        raise ValueError("empty pooling output")
+    return oh, ow
+
+
+def maxpool_fwd(x, k, stride, pads, want_index=True):
+    hipk.require(x, BF16, "x")
+    oh, ow = pool_out_shape(x.shape, k, stride, pads)
+    p = _pool_args(x.shape, k, stride, pads, oh, ow)
+    y = torch.empty((x.shape[0], oh, ow, x.shape[3]), dtype=BF16, device=x.device)
+    idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device) if want_index else None
+    hipk.check(hipk.lib().dtfa_maxpool_fwd(x.data_ptr(), y.data_ptr(), hipk.ptr(idx), C.byref(p), hipk.stream()),
+               "maxpool_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, x_shape, k, stride, pads):
+    hipk.require(dy, BF16, "dy")
+    hipk.require(idx, torch.uint8, "idx")
+    oh, ow = pool_out_shape(x_shape, k, stride, pads)
+    if tuple(dy.shape) != (x_shape[0], oh, ow, x_shape[3]) or idx.shape != dy.shape:
+        raise ValueError("maxpool_bwd shapes")
+    p = _pool_args(x_shape, k, stride, pads, oh, ow)
+    dx = torch.empty(tuple(x_shape), dtype=BF16, device=dy.device)
+    hipk.check(hipk.lib().dtfa_maxpool_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), C.byref(p), hipk.stream()),
+               "maxpool_bwd")
+    return dx
+
+
+def avgpool_fwd(x, k, stride, pads, include_pad=False):
+    hipk.require(x, BF16, "x")
+    oh, ow = pool_out_shape(x.shape, k, stride, pads)
+    p = _pool_args(x.shape, k, stride, pads, oh, ow, include_pad)
+    y = torch.empty((x.shape[0], oh, ow, x.shape[3]), dtype=BF16, device=x.device)
+    hipk.check(hipk.lib().dtfa_avgpool_fwd(x.data_ptr(), y.data_ptr(), C.byref(p), hipk.stream()), "avgpool_fwd")
+    return y
+
+
+def avgpool_bwd(dy, x_shape, k, stride, pads, include_pad=False):
+    hipk.require(dy, BF16, "dy")
+    oh, ow = pool_out_shape(x_shape, k, stride, pads)
+    if tuple(dy.shape) != (x_shape[0], oh, ow, x_shape[3]):
+        raise ValueError("avgpool_bwd shapes")
+    p = _pool_args(x_shape, k, stride, pads, oh, ow, include_pad)
+    dx = torch.empty(tuple(x_shape), dtype=BF16, device=dy.device)
+    hipk.check(hipk.lib().dtfa_avgpool_bwd(dy.data_ptr(), dx.data_ptr(), C.byref(p), hipk.stream()), "avgpool_bwd")
+    return dx
+
+
+def gap_fwd(x):
+    hipk.require(x, BF16, "x")
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, Cc), dtype=BF16, device=x.device)
+    hipk.check(hipk.lib().dtfa_gap_fwd(x.data_ptr(), y.data_ptr(), B, H * W, Cc, hipk.stream()), "gap_fwd")
+    return y
+
+
+def gap_bwd(dy, x_shape):
+    hipk.require(dy, BF16, "dy")
+    B, H, W, Cc = x_shape
+    if tuple(dy.shape) != (B, Cc):
+        raise ValueError("gap_bwd shapes")
+    dx = torch.empty(tuple(x_shape), dtype=BF16, device=dy.device)
+    hipk.check(hipk.lib().dtfa_gap_bwd(dy.data_ptr(), dx.data_ptr(), B, H * W, Cc, hipk.stream()), "gap_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------ loss
+def softmax_xent(logits: torch.Tensor, labels: torch.Tensor, n_classes: int, grad_scale: float, act_l2: float = 0.0,
+                 want_grad: bool = True):
+    """logits [B, ld] bf16 (ld >= n_classes), labels [B] int32.
+    Returns (loss[B] f32, dlogits[B, ld] bf16 or None, top1[B] i32, score[B] f32, correct[B] i32)."""
+    hipk.require(logits, BF16, "logits")
+    hipk.require(labels, torch.int32, "labels")
+    B, ld = logits.shape
+    if labels.numel() != B or not (1 <= n_classes <= ld):
+        raise ValueError("softmax_xent shapes")
+    dev = logits.device
+    loss = torch.empty(B, dtype=F32, device=dev)
+    score = torch.empty(B, dtype=F32, device=dev)
+    top1 = torch.empty(B, dtype=torch.int32, device=dev)
+    correct = torch.empty(B, dtype=torch.int32, device=dev)
+    dl = torch.empty_like(logits) if want_grad else None
+    hipk.check(hipk.lib().dtfa_softmax_xent(logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), hipk.ptr(dl),
+                                            top1.data_ptr(), score.data_ptr(), correct.data_ptr(), B, n_classes, ld,
+                                            float(grad_scale), float(act_l2), hipk.stream()), "softmax_xent")
+    return loss, dl, top1, score, correct
+
+
+def mean_f32(v: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    hipk.require(v, F32, "v")
+    out = torch.empty(1, dtype=F32, device=v.device)
+    hipk.check(hipk.lib().dtfa_mean_f32(v.data_ptr(), out.data_ptr(), v.numel(), float(scale), hipk.stream()), "mean")
+    return out
+
+
+# ------------------------------------------------------------------ dropout
+def dropout(x: torch.Tensor, rate: float, seed: int) -> torch.Tensor:
+    hipk.require(x, BF16, "x")
+    y = torch.empty_like(x)
+    hipk.check(hipk.lib().dtfa_dropout(x.data_ptr(), y.data_ptr(), x.numel(), seed & ((1 << 64) - 1), float(rate),
+                                       hipk.stream()), "dropout")
+    return y
+
+
+# ------------------------------------------------------------------ optimizers
+def adam_step(w, m, v, g, w16, hyper, b1, b2, eps):
+    for t, nm in ((w, "w"), (m, "m"), (v, "v")):
+        hipk.require(t, F32, nm)
+    n = w.numel()
+    if m.numel() != n or v.numel() != n or g.numel() != n:
+        raise ValueError("adam_step sizes")
+    if g.dtype not in (F32, BF16) or not g.is_contiguous():
+        raise ValueError("adam_step gradient dtype")
+    if w16 is not None:
+        hipk.require(w16, BF16, "w16")
+        if w16.numel() != n:
+            raise ValueError("adam_step shadow size")
+    hipk.require(hyper, F32, "hyper")
+    hipk.check(hipk.lib().dtfa_adam(w.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(),
+                                    1 if g.dtype == BF16 else 0, hipk.ptr(w16), n, hyper.data_ptr(), float(b1),
+                                    float(b2), float(eps), hipk.stream()), "adam")
+
+
+def momentum_step(w, buf, g, w16, hyper, mu, wd, nesterov):
+    hipk.require(w, F32, "w")
+    hipk.require(buf, F32, "buf")
+    n = w.numel()
+    if buf.numel() != n or g.numel() != n:
+        raise ValueError("momentum_step sizes")
+    if g.dtype not in (F32, BF16) or not g.is_contiguous():
+        raise ValueError("momentum_step gradient dtype")
+    if w16 is not None:
+        hipk.require(w16, BF16, "w16")
+    hipk.require(hyper, F32, "hyper")
+    hipk.check(hipk.lib().dtfa_momentum(w.data_ptr(), buf.data_ptr(), g.data_ptr(), 1 if g.dtype == BF16 else 0,
+                                        hipk.ptr(w16), n, hyper.data_ptr(), float(mu), float(wd),
+                                        1 if nesterov else 0, hipk.stream()), "momentum")
+
+
+def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor) -> None:
+    hipk.require(src, F32, "src")
+    hipk.require(dst, BF16, "dst")
+    if src.numel() != dst.numel():
+        raise ValueError("cast sizes")
+    hipk.check(hipk.lib().dtfa_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), hipk.stream()), "cast")

@@ -1,0 +1,105 @@
+"""HIP implicit-GEMM convolution kernels vs a plain PyTorch fp32 reference."""
+import pytest
+import torch
+
+from distributed_tensorflow_amd.ops import conv as cv
+from distributed_tensorflow_amd.ops import ref
+
+pytestmark = pytest.mark.gpu
+
+# (B, H, W, Cin, Cout, kh, kw, sy, sx, padding)
+CASES = [
+    (2, 8, 8, 8, 8, 1, 1, 1, 1, "VALID"),
+    (2, 9, 11, 16, 24, 3, 3, 1, 1, "SAME"),
+    (3, 15, 15, 8, 32, 3, 3, 2, 2, "VALID"),       # inception stem style
+    (2, 17, 17, 64, 64, 3, 3, 1, 1, (1, 1, 1, 1)),  # resnet 3x3
+    (2, 16, 16, 64, 128, 3, 3, 2, 2, (1, 1, 1, 1)),  # resnet stride-2 3x3
+    (2, 14, 14, 128, 256, 1, 1, 2, 2, "VALID"),     # resnet downsample 1x1 s2
+    (2, 23, 23, 8, 64, 7, 7, 2, 2, (3, 3, 3, 3)),   # resnet stem (Cin padded to 8)
+    (2, 17, 17, 128, 160, 1, 7, 1, 1, "SAME"),      # inception 1x7
+    (2, 17, 17, 160, 192, 7, 1, 1, 1, "SAME"),      # inception 7x1
+    (1, 35, 35, 48, 64, 5, 5, 1, 1, "SAME"),        # inception 5x5
+    (4, 8, 8, 448, 384, 3, 3, 1, 1, "SAME"),
+    (5, 12, 12, 32, 40, 3, 3, 2, 2, "SAME"),        # odd Cout tile tail, SAME stride 2
+]
+
+
+def _mk(case, seed=0):
+    B, H, W, Cin, Cout, kh, kw, sy, sx, padding = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, kh, kw, Cin, generator=g) / (kh * kw * Cin) ** 0.5
+    pads = cv.resolve_pads(padding, H, W, kh, kw, sy, sx)
+    return x, w, pads
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd(case):
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case)
+    xb, wb = x.bfloat16(), w.bfloat16()
+    want = ref.conv2d(xb.float(), wb.float(), (sy, sx), pads)
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    y, part = cv.conv_fwd(xb.cuda(), wb.cuda(), plan, want_stats=True)
+    torch.cuda.synchronize()
+    got = y.float().cpu()
+    assert got.shape == want.shape
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2)
+    # fused batch-norm partial statistics equal the statistics of the stored bf16 output
+    s = part.sum(0).cpu()
+    flat = got.reshape(-1, Cout)
+    torch.testing.assert_close(s[0], flat.sum(0), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(s[1], (flat * flat).sum(0), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bias_relu(case):
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case, 1)
+    xb, wb = x.bfloat16(), w.bfloat16()
+    bias = torch.randn(Cout)
+    want = ref.conv2d(xb.float(), wb.float(), (sy, sx), pads, bias=bias, relu=True)
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    y, _ = cv.conv_fwd(xb.cuda(), wb.cuda(), plan, bias=bias.cuda(), relu=True)
+    torch.testing.assert_close(y.float().cpu(), want, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_backward(case):
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case, 2)
+    xb = x.bfloat16().float().requires_grad_(True)
+    wb = w.bfloat16().float().requires_grad_(True)
+    y = ref.conv2d(xb, wb, (sy, sx), pads)
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(y.shape, generator=g).bfloat16()
+    y.backward(dy.float())
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    dx = cv.conv_dgrad(dy.cuda(), wb.detach().bfloat16().cuda(), plan)
+    dw = cv.conv_wgrad(xb.detach().bfloat16().cuda(), dy.cuda(), plan)
+    torch.cuda.synchronize()
+    scale_x = xb.grad.abs().max().item() + 1e-6
+    scale_w = wb.grad.abs().max().item() + 1e-6
+    assert (dx.float().cpu() - xb.grad).abs().max().item() <= 2e-2 * scale_x
+    assert (dw.cpu() - wb.grad).abs().max().item() <= 2e-2 * scale_w
+
+
+def test_conv_large_tiles():
+    # exercises the 128x128 / 256x128 tiles, BK=64 and multi-split wgrad
+    case = (16, 28, 28, 128, 128, 3, 3, 1, 1, "SAME")
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case, 5)
+    xb, wb = x.bfloat16(), w.bfloat16()
+    want = ref.conv2d(xb.float(), wb.float(), (sy, sx), pads)
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    y, _ = cv.conv_fwd(xb.cuda(), wb.cuda(), plan)
+    torch.testing.assert_close(y.float().cpu(), want, rtol=2e-2, atol=2e-2)
+    g = torch.Generator().manual_seed(6)
+    dy = torch.randn(want.shape, generator=g).bfloat16()
+    xr = xb.float().requires_grad_(True)
+    wr = wb.float().requires_grad_(True)
+    ref.conv2d(xr, wr, (sy, sx), pads).backward(dy.float())
+    dx = cv.conv_dgrad(dy.cuda(), wb.cuda(), plan)
+    dw = cv.conv_wgrad(xb.cuda(), dy.cuda(), plan)
+    assert (dx.float().cpu() - xr.grad).abs().max().item() <= 2e-2 * xr.grad.abs().max().item()
+    assert (dw.cpu() - wr.grad).abs().max().item() <= 2e-2 * wr.grad.abs().max().item()

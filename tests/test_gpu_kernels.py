@@ -1,0 +1,183 @@
+"""Non-convolution HIP kernels vs plain PyTorch fp32 references."""
+import math
+
+import pytest
+import torch
+
+from distributed_tensorflow_amd.ops import kernels as K
+from distributed_tensorflow_amd.ops import ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0, shift=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale + shift).bfloat16()
+
+
+@pytest.mark.parametrize("shape", [(4, 7, 7, 64), (2, 5, 9, 48), (37, 3, 3, 2048), (64, 28, 28, 64)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+def test_bn_forward_backward(shape, relu, res):
+    C = shape[-1]
+    y = _rand(*shape, seed=1, scale=1.5, shift=0.3)
+    r = _rand(*shape, seed=2) if res else None
+    gamma = torch.rand(C) + 0.5
+    beta = torch.randn(C) * 0.1
+    eps, mom = 1e-3, 0.1
+    rm, rv = torch.zeros(C), torch.ones(C)
+    # reference
+    yf = y.float().requires_grad_(True)
+    gf, bf = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rf = r.float().requires_grad_(True) if res else None
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    out, mean, invstd = ref.batch_norm_train(yf, gf, bf, rm_ref, rv_ref, eps, mom)
+    if res:
+        out = out + rf
+    if relu:
+        out = torch.relu(out)
+    dz = _rand(*shape, seed=3)
+    out.backward(dz.float())
+    # kernels
+    yc = y.cuda()
+    part = K.bn_stats_partials(yc)
+    rmc, rvc = rm.cuda(), rv.cuda()
+    m, i, sc, sh = K.bn_finalize(part, yc.numel() // C, eps, gamma.cuda(), beta.cuda(), rmc, rvc, mom)
+    z = K.bn_apply(yc, sc, sh, relu, r.cuda() if res else None)
+    torch.testing.assert_close(m.cpu(), mean.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(i.cpu(), invstd.detach(), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(rmc.cpu(), rm_ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rvc.cpu(), rv_ref, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(z.float().cpu(), out.detach(), rtol=2e-2, atol=2e-2)
+    dy, dres, dgamma, dbeta = K.bn_backward(dz.cuda(), yc, z, m, i, gamma.cuda(), relu, res)
+    # the reference masks with its own fp32 output; mask from the bf16 output can differ only at |out| ~ 0
+    tol = 3e-2 * (yf.grad.abs().max().item() + 1e-6)
+    assert (dy.float().cpu() - yf.grad).abs().max().item() <= tol
+    torch.testing.assert_close(dgamma.cpu(), gf.grad, rtol=2e-2, atol=2e-2 * gf.grad.abs().max().item())
+    torch.testing.assert_close(dbeta.cpu(), bf.grad, rtol=2e-2, atol=2e-2 * bf.grad.abs().max().item())
+    if res:
+        assert (dres.float().cpu() - rf.grad).abs().max().item() <= 2e-2 * rf.grad.abs().max().item()
+
+
+def test_bn_eval_coeffs():
+    C = 96
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C)
+    rm, rv = torch.randn(C), torch.rand(C) + 0.2
+    sc, sh = K.bn_eval_coeffs(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), 1e-3)
+    y = _rand(3, 4, 4, C, seed=4)
+    want = ref.batch_norm_eval(y.float(), gamma, beta, rm, rv, 1e-3)
+    got = K.bn_apply(y.cuda(), sc, sh, False)
+    torch.testing.assert_close(got.float().cpu(), want, rtol=2e-2, atol=2e-2)
+
+
+POOLS = [
+    ((2, 15, 15, 16), (3, 3), (2, 2), (0, 0, 0, 0)),
+    ((2, 14, 14, 64), (3, 3), (2, 2), (1, 1, 1, 1)),
+    ((3, 9, 7, 24), (3, 3), (1, 1), (1, 1, 1, 1)),
+    ((1, 8, 8, 32), (2, 2), (2, 2), (0, 0, 0, 0)),
+]
+
+
+@pytest.mark.parametrize("shape,k,s,pads", POOLS)
+def test_maxpool(shape, k, s, pads):
+    x = _rand(*shape, seed=5)
+    xf = x.float().requires_grad_(True)
+    want = ref.max_pool(xf, k, s, pads)
+    dy = _rand(*want.shape, seed=6)
+    want.backward(dy.float())
+    y, idx = K.maxpool_fwd(x.cuda(), k, s, pads)
+    torch.testing.assert_close(y.float().cpu(), want.detach(), rtol=0, atol=0)
+    dx = K.maxpool_bwd(dy.cuda(), idx, shape, k, s, pads)
+    torch.testing.assert_close(dx.float().cpu(), xf.grad, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("shape,k,s,pads", POOLS)
+@pytest.mark.parametrize("include_pad", [False, True])
+def test_avgpool(shape, k, s, pads, include_pad):
+    x = _rand(*shape, seed=7)
+    xf = x.float().requires_grad_(True)
+    want = ref.avg_pool(xf, k, s, pads, include_pad)
+    dy = _rand(*want.shape, seed=8)
+    want.backward(dy.float())
+    y = K.avgpool_fwd(x.cuda(), k, s, pads, include_pad)
+    torch.testing.assert_close(y.float().cpu(), want.detach(), rtol=1e-2, atol=1e-2)
+    dx = K.avgpool_bwd(dy.cuda(), shape, k, s, pads, include_pad)
+    torch.testing.assert_close(dx.float().cpu(), xf.grad, rtol=1e-2, atol=1e-2)
+
+
+def test_global_avg_pool():
+    x = _rand(5, 8, 8, 2048, seed=9)
+    y = K.gap_fwd(x.cuda())
+    torch.testing.assert_close(y.float().cpu(), x.float().mean((1, 2)), rtol=1e-2, atol=1e-2)
+    dy = _rand(5, 2048, seed=10)
+    dx = K.gap_bwd(dy.cuda(), x.shape)
+    want = (dy.float() / 64)[:, None, None, :].expand(5, 8, 8, 2048)
+    torch.testing.assert_close(dx.float().cpu(), want, rtol=1e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,n,ld", [(32, 5, 8), (7, 1001, 1008), (64, 64, 64)])
+def test_softmax_xent(B, n, ld):
+    logits = _rand(B, ld, seed=11, scale=3.0)
+    labels = torch.randint(0, n, (B,), dtype=torch.int32)
+    lf = logits.float().requires_grad_(True)
+    loss, top1, score, correct = ref.softmax_xent(lf, labels, n, act_l2=5e-4)
+    loss.mean().backward()
+    l, dl, t1, sc, co = K.softmax_xent(logits.cuda(), labels.cuda(), n, 1.0 / B, act_l2=5e-4)
+    torch.testing.assert_close(l.cpu(), loss.detach(), rtol=1e-3, atol=1e-3)
+    assert torch.equal(t1.cpu(), top1)
+    assert torch.equal(co.cpu(), correct)
+    torch.testing.assert_close(sc.cpu(), score.detach(), rtol=0, atol=0)
+    torch.testing.assert_close(dl.float().cpu(), lf.grad, rtol=2e-2, atol=1e-4)
+    m = K.mean_f32(l)
+    torch.testing.assert_close(m.cpu()[0], loss.mean().detach(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("gdtype", [torch.float32, torch.bfloat16])
+def test_adam_matches_tf1_formula(gdtype):
+    n = 100003
+    g = torch.Generator().manual_seed(12)
+    w = torch.randn(n, generator=g)
+    m = torch.zeros(n)
+    v = torch.zeros(n)
+    wc, mc, vc = w.cuda(), m.cuda(), v.cuda()
+    w16 = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    for t in range(1, 4):
+        grad = torch.randn(n, generator=g).to(gdtype)
+        gf = grad.float()
+        lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        m = b1 * m + (1 - b1) * gf
+        v = b2 * v + (1 - b2) * gf * gf
+        w = w - lr_t * m / (v.sqrt() + eps)
+        hyper = torch.tensor([lr_t, 1.0], dtype=torch.float32, device="cuda")
+        K.adam_step(wc, mc, vc, grad.cuda(), w16, hyper, b1, b2, eps)
+    torch.testing.assert_close(wc.cpu(), w, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(w16.float().cpu(), wc.cpu().bfloat16().float(), rtol=0, atol=0)
+
+
+def test_momentum_sgd():
+    n = 4099
+    g = torch.Generator().manual_seed(13)
+    w = torch.randn(n, generator=g)
+    p = torch.nn.Parameter(w.clone())
+    opt = torch.optim.SGD([p], lr=0.1, momentum=0.9, weight_decay=1e-4)
+    wc, buf = w.cuda(), torch.zeros(n, device="cuda")
+    hyper = torch.tensor([0.1, 1.0], dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        grad = torch.randn(n, generator=g)
+        p.grad = grad.clone()
+        opt.step()
+        K.momentum_step(wc, buf, grad.cuda(), None, hyper, 0.9, 1e-4, False)
+    torch.testing.assert_close(wc.cpu(), p.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_dropout_deterministic_and_unbiased():
+    x = torch.ones(1 << 16, dtype=torch.bfloat16, device="cuda")
+    a = K.dropout(x, 0.5, seed=1234)
+    b = K.dropout(x, 0.5, seed=1234)
+    c = K.dropout(x, 0.5, seed=99)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    kept = (a != 0).float().mean().item()
+    assert abs(kept - 0.5) < 0.02
+    assert abs(a.float().mean().item() - 1.0) < 0.04
+    d = K.dropout(x, 0.8, seed=5)
+    assert abs((d != 0).float().mean().item() - 0.2) < 0.02
