@@ -1,0 +1,133 @@
+#!/usr/bin/env python
+"""Headline benchmark: training throughput (images/sec, whole job) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--model resnet50|flower_cnn|inception_v3_head]
+                    [--mode sync_dp|sharded_ps|async_ssp] [--batch PER_GPU_BATCH]
+
+For N > 1 launch one rank per GPU with ``python -m torch.distributed.run`` (RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the environment); collectives
+run over RCCL.  Every timed step is a complete training step: forward,
+backward, gradient collective, fused optimizer update.  Data is synthetic
+(5-class flower_photos-shaped images, random-init weights); compute dtype is
+bf16 with fp32 master weights and fp32 accumulation.  Rank 0 prints one JSON
+line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from distributed_tensorflow_amd.models import build_model  # noqa: E402
+from distributed_tensorflow_amd.ops import functional as F  # noqa: E402
+from distributed_tensorflow_amd.parallel.engine import DataParallelEngine  # noqa: E402
+
+DEFAULT_BATCH = {"resnet50": 256, "flower_cnn": 512, "inception_v3_head": 128}
+IMAGE_SIZE = {"resnet50": 224, "flower_cnn": 224, "inception_v3_head": 299}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="resnet50", choices=sorted(DEFAULT_BATCH))
+    ap.add_argument("--mode", default="sync_dp", choices=["sync_dp", "sharded_ps", "async_ssp"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default depends on the model)")
+    ap.add_argument("--bucket_mb", type=float, default=32.0)
+    ap.add_argument("--staleness", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d; reporting WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    batch = args.batch or DEFAULT_BATCH[args.model]
+    size = IMAGE_SIZE[args.model]
+    torch.manual_seed(1234)
+    model = build_model(args.model, num_classes=5, device=device)
+    model.train()
+    if args.model == "inception_v3_head":
+        opt, lr, okw = "adam", 1e-3, {}
+    else:
+        opt, lr, okw = "momentum", 0.1 * batch * world / 256.0, {"momentum": 0.9, "weight_decay": 1e-4}
+    engine = DataParallelEngine(model, mode=args.mode, optimizer=opt, lr=lr, opt_kwargs=okw,
+                                bucket_mb=args.bucket_mb, staleness=args.staleness)
+
+    g = torch.Generator(device="cpu").manual_seed(rank)
+    images = torch.zeros(batch, size, size, 8)
+    images[..., :3] = torch.rand(batch, size, size, 3, generator=g) * 2 - 1
+    images = images.to(device=device, dtype=torch.bfloat16)
+    labels = torch.randint(0, 5, (batch,), generator=g).to(device=device, dtype=torch.int32)
+
+    def step():
+        engine.begin_step()
+        out = model(images)
+        logits, reg = out if isinstance(out, tuple) else (out, None)
+        loss, _, _, _ = F.softmax_xent(logits, labels, 5)
+        total = loss if reg is None else loss + reg
+        total.backward()
+        engine.finish_step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    ips = batch * world * args.steps / dt
+    if rank == 0:
+        print(json.dumps({
+            "metric": "train images/sec (whole node)",
+            "value": round(ips, 2),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "final_loss": round(float(loss.item()), 4),
+            "config": {"model": args.model, "global_batch": batch * world, "per_gpu_batch": batch,
+                       "image_size": size, "num_classes": 5, "parallelism": "dp%d" % world, "mode": args.mode,
+                       "optimizer": opt},
+        }), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

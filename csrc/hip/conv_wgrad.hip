@@ -210,35 +210,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     }
 }
 
-// Sum the split slabs in split order; write (or accumulate into) the gradient.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, size_t n,
-                                    float* __restrict__ out_f32, bf16* __restrict__ out_bf16,
-                                    int accumulate) {
-  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= n) return;
-  if (i + 4 <= n) {
-    float4 s = *(const float4*)(slab + i);
-    for (int k = 1; k < splits; ++k) {
-      float4 v = *(const float4*)(slab + (size_t)k * n + i);
+// Sum the split slabs; write (or accumulate into) the gradient.  Block = 64
+// float4 columns x 16 split lanes: lane sl sums splits sl, sl+16, ... and the 16
+// partial sums are combined through LDS in lane order, so the result does not
+// depend on scheduling.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, size_t n,
+                                                            float* __restrict__ out_f32, bf16* __restrict__ out_bf16,
+                                                            int accumulate) {
+  __shared__ float4 red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const size_t i = ((size_t)blockIdx.x * 64 + tx) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n) {
+    if (i + 4 <= n) {
+      for (int k = ty; k < splits; k += 16) {
+        float4 v = *(const float4*)(slab + (size_t)k * n + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    } else {
+      float* sp = &s.x;
+      for (int k = ty; k < splits; k += 16)
+        for (size_t e = i; e < n; ++e) sp[e - i] += slab[(size_t)k * n + e];
+    }
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < n) {
+    for (int t = 1; t < 16; ++t) {
+      float4 v = red[t][tx];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    if (out_f32) {
-      if (accumulate) {
-        float4 o = *(float4*)(out_f32 + i);
-        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    float* sp = &s.x;
+    for (int e = 0; e < 4 && i + e < n; ++e) {
+      float r = sp[e];
+      if (out_f32) {
+        if (accumulate) r += out_f32[i + e];
+        out_f32[i + e] = r;
       }
-      *(float4*)(out_f32 + i) = s;
-    }
-    if (out_bf16) {
-      out_bf16[i] = (bf16)s.x; out_bf16[i + 1] = (bf16)s.y;
-      out_bf16[i + 2] = (bf16)s.z; out_bf16[i + 3] = (bf16)s.w;
-    }
-  } else {
-    for (; i < n; ++i) {
-      float s = 0.f;
-      for (int k = 0; k < splits; ++k) s += slab[(size_t)k * n + i];
-      if (out_f32) out_f32[i] = accumulate ? out_f32[i] + s : s;
-      if (out_bf16) out_bf16[i] = (bf16)s;
+      if (out_bf16) out_bf16[i + e] = (bf16)r;
     }
   }
 }
@@ -281,9 +290,9 @@ extern "C" int dtfa_conv_wgrad(WgradArgs* a, int bmw, int bnw, int bkp, int spli
 extern "C" int dtfa_wgrad_reduce(const float* slab, int splits, long long n, float* out_f32, void* out_bf16,
                                  int accumulate, hipStream_t stream) {
   if (n <= 0) return 0;
-  size_t threads = ((size_t)n + 3) / 4;
-  unsigned blocks = (unsigned)((threads + 255) / 256);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, splits, (size_t)n, out_f32,
+  size_t vecs = ((size_t)n + 3) / 4;
+  unsigned blocks = (unsigned)((vecs + 63) / 64);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(1024), 0, stream, slab, splits, (size_t)n, out_f32,
                      (bf16*)out_bf16, accumulate);
   return (int)hipGetLastError();
 }

@@ -1,0 +1,318 @@
+"""Differentiable ops.
+
+GPU tensors run the gfx950 HIP kernels through ``torch.autograd.Function``
+wrappers (there is no other GPU implementation: a missing kernel library is
+an error).  CPU tensors run the fp32 reference ops in :mod:`ops.ref`, which is
+what the CPU plumbing configurations and the numerics tests use.
+
+Layout conventions: activations ``[B, H, W, C]`` (NHWC, contiguous), conv
+weights ``[Cout, KH, KW, Cin]``, dense weights ``[Out, In]``.  On the GPU
+activations and conv/dense weights are bf16; batch-norm parameters, biases and
+statistics are fp32.
+
+Weight gradients: when a parameter carries a ``main_grad`` attribute (an fp32
+view into a flat gradient bucket, installed by ``parallel.flat.FlatParams``)
+the backward kernels write the gradient straight into it, mark
+``_grad_filled`` and fire ``_grad_ready_cb`` (used to launch bucketed
+collectives while the rest of the backward pass is still running); autograd
+then sees ``None`` for that input.  Without ``main_grad`` the gradient is
+returned to autograd in the parameter's dtype.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import conv as cv
+from . import kernels as K
+from . import ref
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+# ----------------------------------------------------------------------------
+# gradient delivery
+# ----------------------------------------------------------------------------
+def _notify(param) -> None:
+    first = not getattr(param, "_grad_filled", False)
+    param._grad_filled = True
+    cb = getattr(param, "_grad_ready_cb", None)
+    if first and cb is not None:
+        cb(param)
+
+
+def _deliver_small(param, grad: Optional[torch.Tensor]):
+    """fp32 per-channel gradients (gamma / beta / bias)."""
+    if param is None or grad is None:
+        return None
+    mg = getattr(param, "main_grad", None)
+    if mg is None:
+        return grad.to(param.dtype).view_as(param)
+    if getattr(param, "_grad_filled", False):
+        mg.add_(grad.view_as(mg))
+    else:
+        mg.copy_(grad.view_as(mg))
+    _notify(param)
+    return None
+
+
+def _deliver_wgrad(param, x, dy, plan):
+    mg = getattr(param, "main_grad", None)
+    if mg is not None:
+        cv.conv_wgrad(x, dy, plan, out=mg, accumulate=getattr(param, "_grad_filled", False))
+        _notify(param)
+        return None
+    out = torch.empty(param.shape, dtype=param.dtype, device=param.device)
+    cv.conv_wgrad(x, dy, plan, out=out)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# conv + batch-norm (+ residual) (+ ReLU)
+# ----------------------------------------------------------------------------
+class _ConvBnActFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, plan, run_mean, run_var, eps, momentum, relu, training,
+                params):
+        need_grad = any(ctx.needs_input_grad)
+        y, part = cv.conv_fwd(x, weight, plan, want_stats=training)
+        M = y.numel() // plan.cout
+        if training:
+            mean, invstd, scale, shift = K.bn_finalize(part, M, eps, gamma, beta, run_mean, run_var, momentum)
+        else:
+            scale, shift = K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
+            mean = invstd = None
+        z = K.bn_apply(y, scale, shift, relu, residual)
+        ctx.plan, ctx.relu, ctx.training = plan, relu, training
+        ctx.has_res = residual is not None
+        ctx.params = params  # (weight_param, gamma_param, beta_param) python objects
+        if need_grad:
+            ctx.save_for_backward(x, weight, y, z if relu else None, gamma, mean, invstd, scale)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight, y, z, gamma, mean, invstd, scale = ctx.saved_tensors
+        plan = ctx.plan
+        wparam, gparam, bparam = ctx.params
+        dz = dz.contiguous()
+        want_dres = ctx.has_res and ctx.needs_input_grad[4]
+        if ctx.training:
+            dy, dres, dgamma, dbeta = K.bn_backward(dz, y, z, mean, invstd, gamma, ctx.relu, want_dres)
+        else:
+            g = K.relu_bwd(dz, z) if ctx.relu else dz
+            dres = g if want_dres else None
+            dy = (g.float() * scale).to(BF16)
+            dgamma = dbeta = None
+            if gamma is not None and ctx.needs_input_grad[2]:
+                raise NotImplementedError("gradients of frozen-statistics batch-norm parameters")
+        gx = gw = gg = gb = None
+        if ctx.needs_input_grad[1]:
+            gw = _deliver_wgrad(wparam if wparam is not None else weight, x, dy, plan)
+        if gamma is not None and ctx.needs_input_grad[2]:
+            gg = _deliver_small(gparam if gparam is not None else gamma, dgamma)
+        if ctx.needs_input_grad[3]:
+            gb = _deliver_small(bparam, dbeta) if bparam is not None else dbeta
+        if ctx.needs_input_grad[0]:
+            gx = cv.conv_dgrad(dy, weight, plan)
+        return gx, gw, gg, gb, dres, None, None, None, None, None, None, None, None
+
+
+def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, eps, momentum, relu, training,
+                residual=None):
+    """``act(bn(conv(x, weight)) + residual)``; batch statistics when ``training``."""
+    kh, kw = weight.shape[1], weight.shape[2]
+    sy, sx = stride
+    pads = cv.resolve_pads(padding, x.shape[1], x.shape[2], kh, kw, sy, sx)
+    if not x.is_cuda:
+        y = ref.conv2d(x, weight, (sy, sx), pads)
+        if training:
+            z, _, _ = ref.batch_norm_train(y, gamma, beta, run_mean, run_var, eps, momentum)
+        else:
+            z = ref.batch_norm_eval(y, gamma, beta, run_mean, run_var, eps)
+        if residual is not None:
+            z = z + residual
+        return torch.relu(z) if relu else z
+    plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], weight.shape[0], kh, kw, sy, sx, pads, x.device)
+    return _ConvBnActFn.apply(x, weight, gamma, beta, residual, plan, run_mean, run_var, eps, momentum, relu,
+                              training, (weight, gamma, beta))
+
+
+# ----------------------------------------------------------------------------
+# plain conv (+bias) (+ReLU)
+# ----------------------------------------------------------------------------
+class _ConvFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, plan, relu, params):
+        y, _ = cv.conv_fwd(x, weight, plan, bias=bias, relu=relu)
+        ctx.plan, ctx.relu, ctx.params = plan, relu, params
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        plan = ctx.plan
+        wparam, bparam = ctx.params
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = K.relu_bwd(dy, y)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[1]:
+            gw = _deliver_wgrad(wparam, x, dy, plan)
+            if gw is not None:
+                gw = gw.view(weight.shape)
+        if bparam is not None and ctx.needs_input_grad[2]:
+            gb = _deliver_small(bparam, dy.reshape(-1, plan.cout).float().sum(0))
+        if ctx.needs_input_grad[0]:
+            gx = cv.conv_dgrad(dy, weight, plan)
+        return gx, gw, gb, None, None, None
+
+
+def conv2d(x, weight, bias=None, *, stride=(1, 1), padding="VALID", relu=False):
+    kh, kw = weight.shape[1], weight.shape[2]
+    sy, sx = stride
+    pads = cv.resolve_pads(padding, x.shape[1], x.shape[2], kh, kw, sy, sx)
+    if not x.is_cuda:
+        return ref.conv2d(x, weight, (sy, sx), pads, bias, relu)
+    plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], weight.shape[0], kh, kw, sy, sx, pads, x.device)
+    return _ConvFn.apply(x, weight, bias, plan, relu, (weight, bias))
+
+
+def dense(x, weight, bias=None, *, relu=False):
+    """``x [B, In] @ weight[Out, In]^T + bias``; In and Out multiples of 8 on the GPU."""
+    if not x.is_cuda:
+        return ref.dense(x, weight, bias, relu)
+    B, n_in = x.shape
+    n_out = weight.shape[0]
+    plan = cv.get_plan(1, 1, n_in, n_out, 1, 1, 1, 1, (0, 0, 0, 0), x.device)
+    y = _ConvFn.apply(x.view(B, 1, 1, n_in), weight.view(n_out, 1, 1, n_in), bias, plan, relu, (weight, bias))
+    return y.view(B, n_out)
+
+
+# ----------------------------------------------------------------------------
+# pooling
+# ----------------------------------------------------------------------------
+class _MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pads):
+        need = ctx.needs_input_grad[0]
+        y, idx = K.maxpool_fwd(x, k, stride, pads, want_index=need)
+        ctx.cfg = (tuple(x.shape), k, stride, pads)
+        if need:
+            ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        shape, k, stride, pads = ctx.cfg
+        return K.maxpool_bwd(dy.contiguous(), idx, shape, k, stride, pads), None, None, None
+
+
+class _AvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pads, include_pad):
+        ctx.cfg = (tuple(x.shape), k, stride, pads, include_pad)
+        return K.avgpool_fwd(x, k, stride, pads, include_pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, k, stride, pads, include_pad = ctx.cfg
+        return K.avgpool_bwd(dy.contiguous(), shape, k, stride, pads, include_pad), None, None, None, None
+
+
+class _GapFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return K.gap_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.gap_bwd(dy.contiguous(), ctx.shape)
+
+
+def _pool_pads(x, k, stride, padding):
+    return cv.resolve_pads(padding, x.shape[1], x.shape[2], k[0], k[1], stride[0], stride[1])
+
+
+def max_pool(x, k=(3, 3), stride=(2, 2), padding="VALID"):
+    pads = _pool_pads(x, k, stride, padding)
+    if not x.is_cuda:
+        return ref.max_pool(x, k, stride, pads)
+    return _MaxPoolFn.apply(x, tuple(k), tuple(stride), pads)
+
+
+def avg_pool(x, k=(3, 3), stride=(1, 1), padding="SAME", count_include_pad=False):
+    pads = _pool_pads(x, k, stride, padding)
+    if not x.is_cuda:
+        return ref.avg_pool(x, k, stride, pads, count_include_pad)
+    return _AvgPoolFn.apply(x, tuple(k), tuple(stride), pads, count_include_pad)
+
+
+def global_avg_pool(x):
+    if not x.is_cuda:
+        return ref.global_avg_pool(x)
+    return _GapFn.apply(x)
+
+
+# ----------------------------------------------------------------------------
+# dropout
+# ----------------------------------------------------------------------------
+class _DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, rate, seed):
+        ctx.rate, ctx.seed = rate, seed
+        return K.dropout(x.contiguous(), rate, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.dropout(dy.contiguous(), ctx.rate, ctx.seed), None, None
+
+
+_dropout_counter = [0]
+
+
+def dropout(x, rate: float, training: bool, seed: Optional[int] = None):
+    """Inverted dropout with *drop* probability ``rate``."""
+    if not training or rate <= 0.0:
+        return x
+    if not x.is_cuda:
+        return ref.dropout(x, rate, training)
+    if seed is None:
+        _dropout_counter[0] += 1
+        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _dropout_counter[0] * 0xD1B54A32D192ED03) & ((1 << 64) - 1)
+    return _DropoutFn.apply(x, rate, seed)
+
+
+# ----------------------------------------------------------------------------
+# loss
+# ----------------------------------------------------------------------------
+class _XentFn(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, n_classes, act_l2):
+        B = logits.shape[0]
+        loss, dl, top1, score, correct = K.softmax_xent(logits, labels, n_classes, 1.0 / B, act_l2)
+        ctx.save_for_backward(dl)
+        ctx.mark_non_differentiable(top1, score, correct)
+        return K.mean_f32(loss)[0], top1, score, correct
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        (dl,) = ctx.saved_tensors
+        # dl already holds d(mean loss)/d(logits); g is the upstream scalar (1.0 for a plain .backward()).
+        return (dl.float() * g).to(BF16), None, None, None
+
+
+def softmax_xent(logits, labels, n_classes: Optional[int] = None, act_l2: float = 0.0):
+    """Mean sparse softmax cross-entropy (+ optional L2 activity term on the
+    logits).  Returns ``(loss, top1, top1_score, correct)``."""
+    n = n_classes if n_classes is not None else logits.shape[-1]
+    if not logits.is_cuda:
+        loss, top1, score, correct = ref.softmax_xent(logits, labels, n, act_l2)
+        return loss.mean(), top1, score, correct
+    return _XentFn.apply(logits.contiguous(), labels.to(torch.int32).contiguous(), n, act_l2)
