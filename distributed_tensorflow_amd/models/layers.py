@@ -118,10 +118,10 @@ def cast_for_device(module: nn.Module, device, compute_dtype=None) -> nn.Module:
     if compute_dtype is None:
         compute_dtype = torch.bfloat16 if device.type == "cuda" else torch.float32
     for p in module.parameters():
-        keep = getattr(p, "_keep_fp32", False)
-        flag = keep
+        # 1-D parameters (batch-norm scale/offset, biases) are consumed in fp32 by the kernels
+        keep = p.dim() <= 1
         p.data = p.data.to(device=device, dtype=torch.float32 if keep else compute_dtype)
-        p._keep_fp32 = flag
+        p._keep_fp32 = keep
     for name, b in list(module.named_buffers()):
         b.data = b.data.to(device=device)
     module.compute_dtype = compute_dtype

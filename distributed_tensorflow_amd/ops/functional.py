@@ -32,6 +32,24 @@ from . import ref
 BF16 = torch.bfloat16
 F32 = torch.float32
 
+_force_reference = [False]
+
+
+class reference_mode:
+    """Test/diagnostic context: run the plain PyTorch reference ops even for GPU
+    tensors (used to calibrate bf16 noise against the fp32 CPU oracle)."""
+
+    def __enter__(self):
+        self._old = _force_reference[0]
+        _force_reference[0] = True
+
+    def __exit__(self, *a):
+        _force_reference[0] = self._old
+
+
+def _use_hip(t: torch.Tensor) -> bool:
+    return t.is_cuda and not _force_reference[0]
+
 
 # ----------------------------------------------------------------------------
 # gradient delivery
@@ -127,7 +145,7 @@ def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, e
     kh, kw = weight.shape[1], weight.shape[2]
     sy, sx = stride
     pads = cv.resolve_pads(padding, x.shape[1], x.shape[2], kh, kw, sy, sx)
-    if not x.is_cuda:
+    if not _use_hip(x):
         y = ref.conv2d(x, weight, (sy, sx), pads)
         if training:
             z, _, _ = ref.batch_norm_train(y, gamma, beta, run_mean, run_var, eps, momentum)
@@ -176,7 +194,7 @@ def conv2d(x, weight, bias=None, *, stride=(1, 1), padding="VALID", relu=False):
     kh, kw = weight.shape[1], weight.shape[2]
     sy, sx = stride
     pads = cv.resolve_pads(padding, x.shape[1], x.shape[2], kh, kw, sy, sx)
-    if not x.is_cuda:
+    if not _use_hip(x):
         return ref.conv2d(x, weight, (sy, sx), pads, bias, relu)
     plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], weight.shape[0], kh, kw, sy, sx, pads, x.device)
     return _ConvFn.apply(x, weight, bias, plan, relu, (weight, bias))
@@ -184,7 +202,7 @@ def conv2d(x, weight, bias=None, *, stride=(1, 1), padding="VALID", relu=False):
 
 def dense(x, weight, bias=None, *, relu=False):
     """``x [B, In] @ weight[Out, In]^T + bias``; In and Out multiples of 8 on the GPU."""
-    if not x.is_cuda:
+    if not _use_hip(x):
         return ref.dense(x, weight, bias, relu)
     B, n_in = x.shape
     n_out = weight.shape[0]
@@ -242,20 +260,20 @@ def _pool_pads(x, k, stride, padding):
 
 def max_pool(x, k=(3, 3), stride=(2, 2), padding="VALID"):
     pads = _pool_pads(x, k, stride, padding)
-    if not x.is_cuda:
+    if not _use_hip(x):
         return ref.max_pool(x, k, stride, pads)
     return _MaxPoolFn.apply(x, tuple(k), tuple(stride), pads)
 
 
 def avg_pool(x, k=(3, 3), stride=(1, 1), padding="SAME", count_include_pad=False):
     pads = _pool_pads(x, k, stride, padding)
-    if not x.is_cuda:
+    if not _use_hip(x):
         return ref.avg_pool(x, k, stride, pads, count_include_pad)
     return _AvgPoolFn.apply(x, tuple(k), tuple(stride), pads, count_include_pad)
 
 
 def global_avg_pool(x):
-    if not x.is_cuda:
+    if not _use_hip(x):
         return ref.global_avg_pool(x)
     return _GapFn.apply(x)
 
@@ -281,7 +299,7 @@ def dropout(x, rate: float, training: bool, seed: Optional[int] = None):
     """Inverted dropout with *drop* probability ``rate``."""
     if not training or rate <= 0.0:
         return x
-    if not x.is_cuda:
+    if not _use_hip(x):
         return ref.dropout(x, rate, training)
     if seed is None:
         _dropout_counter[0] += 1
@@ -312,7 +330,7 @@ def softmax_xent(logits, labels, n_classes: Optional[int] = None, act_l2: float 
     """Mean sparse softmax cross-entropy (+ optional L2 activity term on the
     logits).  Returns ``(loss, top1, top1_score, correct)``."""
     n = n_classes if n_classes is not None else logits.shape[-1]
-    if not logits.is_cuda:
+    if not _use_hip(logits):
         loss, top1, score, correct = ref.softmax_xent(logits, labels, n, act_l2)
         return loss.mean(), top1, score, correct
     return _XentFn.apply(logits.contiguous(), labels.to(torch.int32).contiguous(), n, act_l2)

@@ -21,7 +21,7 @@ def conv2d(x, w, stride: Tuple[int, int], pads: Tuple[int, int, int, int], bias=
     xn = x.permute(0, 3, 1, 2)
     if pt or pb or pl or pr:
         xn = F.pad(xn, (pl, pr, pt, pb))
-    y = F.conv2d(xn, w.permute(0, 3, 1, 2), bias, stride=stride)
+    y = F.conv2d(xn, w.permute(0, 3, 1, 2), None if bias is None else bias.to(x.dtype), stride=stride)
     if relu:
         y = F.relu(y)
     return y.permute(0, 2, 3, 1).contiguous()
@@ -88,7 +88,7 @@ def global_avg_pool(x):
 
 def dense(x, w, bias=None, relu=False):
     """x [B, In], w [Out, In]."""
-    y = F.linear(x, w, bias)
+    y = F.linear(x, w, None if bias is None else bias.to(x.dtype))
     return F.relu(y) if relu else y
 
 
