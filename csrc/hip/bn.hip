@@ -50,17 +50,29 @@ extern "C" int dtfa_partial_reduce(const float* in, float* out, int R, int NV, i
 // and updates running_mean / running_var in place:
 //   running = running * (1 - momentum) + batch * momentum  (unbiased variance)
 // ----------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C, float count, float eps,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-                                   float* __restrict__ shift, float* __restrict__ run_mean,
-                                   float* __restrict__ run_var, float momentum) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// Block = 32 channels x 8 row lanes; the row lanes are combined through LDS in a
+// fixed order.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ part, int R, int C, float count, float eps, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+    float* __restrict__ shift, float* __restrict__ run_mean, float* __restrict__ run_var, float momentum) {
+  __shared__ double red[2][8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
   double s = 0.0, ss = 0.0;
-  for (int r = 0; r < R; ++r) {
-    s += (double)part[((size_t)r * 2) * C + c];
-    ss += (double)part[((size_t)r * 2 + 1) * C + c];
+  if (c < C) {
+    for (int r = ty; r < R; r += 8) {
+      s += (double)part[((size_t)r * 2) * C + c];
+      ss += (double)part[((size_t)r * 2 + 1) * C + c];
+    }
+  }
+  red[0][ty][tx] = s;
+  red[1][ty][tx] = ss;
+  __syncthreads();
+  if (ty != 0 || c >= C) return;
+  for (int t = 1; t < 8; ++t) {
+    s += red[0][t][tx];
+    ss += red[1][t][tx];
   }
   double mu = s / count;
   double var = ss / count - mu * mu;
@@ -83,7 +95,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C,
 extern "C" int dtfa_bn_finalize(const float* part, int R, int C, float count, float eps, const float* gamma,
                                 const float* beta, float* mean, float* invstd, float* scale, float* shift,
                                 float* run_mean, float* run_var, float momentum, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, R, C, count, eps, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part, R, C, count, eps, gamma,
                      beta, mean, invstd, scale, shift, run_mean, run_var, momentum);
   return (int)hipGetLastError();
 }
@@ -165,7 +177,8 @@ extern "C" int dtfa_bn_apply(const void* y, const void* res, void* z, const floa
 template <int MODE>
 __global__ void col_partials_kernel(const bf16* __restrict__ a, const bf16* __restrict__ yv,
                                     const bf16* __restrict__ zout, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, float* __restrict__ out, long long M, int C,
+                                    const float* __restrict__ invstd, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, float* __restrict__ out, long long M, int C,
                                     int TX, int rows_per_block, int relu) {
   extern __shared__ float red[];  // [TY][TX][16]
   const int TY = blockDim.x / TX;
@@ -176,12 +189,14 @@ __global__ void col_partials_kernel(const bf16* __restrict__ a, const bf16* __re
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
   if (cg < cvec) {
-    float mu[8], is[8];
+    float mu[8], is[8], sc[8], sh[8];
     if (MODE == 1) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         mu[j] = mean[cg * 8 + j];
         is[j] = invstd[cg * 8 + j];
+        sc[j] = relu == 2 ? scale[cg * 8 + j] : 0.f;
+        sh[j] = relu == 2 ? shift[cg * 8 + j] : 0.f;
       }
     }
     long long r0 = (long long)blockIdx.y * rows_per_block;
@@ -200,11 +215,12 @@ __global__ void col_partials_kernel(const bf16* __restrict__ a, const bf16* __re
       } else {
         bf16x8 yy = *(const bf16x8*)(yv + off);
         bf16x8 zz;
-        if (relu) zz = *(const bf16x8*)(zout + off);
+        if (relu == 1) zz = *(const bf16x8*)(zout + off);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float g = (float)v[j];
-          if (relu && !((float)zz[j] > 0.f)) g = 0.f;
+          if (relu == 1 && !((float)zz[j] > 0.f)) g = 0.f;
+          if (relu == 2 && !((float)yy[j] * sc[j] + sh[j] > 0.f)) g = 0.f;
           float xh = ((float)yy[j] - mu[j]) * is[j];
           s1[j] += g;
           s2[j] += g * xh;
@@ -265,18 +281,22 @@ extern "C" int dtfa_bn_stats_partials(const void* x, float* out, long long M, in
   col_partials_geometry(M, C, &TX, &gx, &gy, &rpb);
   hipLaunchKernelGGL((col_partials_kernel<0>), dim3(gx, gy), dim3(256), 256 * 16 * sizeof(float), st,
                      (const bf16*)x, (const bf16*)nullptr, (const bf16*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, out, M, C, TX, rpb, 0);
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, out, M, C, TX, rpb, 0);
   return (int)hipGetLastError();
 }
 
+// relu: 0 = no activation, 1 = mask from the stored activation output zout,
+//       2 = mask recomputed as (y*scale + shift > 0) (no residual), saving the zout read.
 extern "C" int dtfa_bn_bwd_partials(const void* dz, const void* y, const void* zout, const float* mean,
-                                    const float* invstd, float* out, long long M, int C, int relu,
-                                    hipStream_t st) {
+                                    const float* invstd, const float* scale, const float* shift, float* out,
+                                    long long M, int C, int relu, hipStream_t st) {
   if (C % 8) return -1;
+  if ((relu == 1 && !zout) || (relu == 2 && (!scale || !shift))) return -2;
   int TX, gx, gy, rpb;
   col_partials_geometry(M, C, &TX, &gx, &gy, &rpb);
   hipLaunchKernelGGL((col_partials_kernel<1>), dim3(gx, gy), dim3(256), 256 * 16 * sizeof(float), st,
-                     (const bf16*)dz, (const bf16*)y, (const bf16*)zout, mean, invstd, out, M, C, TX, rpb, relu);
+                     (const bf16*)dz, (const bf16*)y, (const bf16*)zout, mean, invstd, scale, shift, out, M, C, TX,
+                     rpb, relu);
   return (int)hipGetLastError();
 }
 
@@ -287,17 +307,28 @@ extern "C" int dtfa_bn_bwd_partials(const void* dz, const void* y, const void* z
 //   dy = gscale * (g - c1 - xhat*c2),  c1 = sum g / M, c2 = sum g*xhat / M
 //      = ca * g + cb * y + cc
 // ----------------------------------------------------------------------------
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int R, int C, float count,
-                                       const float* __restrict__ gamma, const float* __restrict__ mean,
-                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb,
-                                       float* __restrict__ cc, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const float* __restrict__ part, int R, int C, float count, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc,
+    int accumulate) {
+  __shared__ double red[2][8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
   double s = 0.0, sx = 0.0;
-  for (int r = 0; r < R; ++r) {
-    s += (double)part[((size_t)r * 2) * C + c];
-    sx += (double)part[((size_t)r * 2 + 1) * C + c];
+  if (c < C) {
+    for (int r = ty; r < R; r += 8) {
+      s += (double)part[((size_t)r * 2) * C + c];
+      sx += (double)part[((size_t)r * 2 + 1) * C + c];
+    }
+  }
+  red[0][ty][tx] = s;
+  red[1][ty][tx] = sx;
+  __syncthreads();
+  if (ty != 0 || c >= C) return;
+  for (int t = 1; t < 8; ++t) {
+    s += red[0][t][tx];
+    sx += red[1][t][tx];
   }
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
@@ -312,7 +343,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int R, in
 extern "C" int dtfa_bn_bwd_finalize(const float* part, int R, int C, float count, const float* gamma,
                                     const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                     float* ca, float* cb, float* cc, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, R, C, count, gamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part, R, C, count, gamma,
                      mean, invstd, dgamma, dbeta, ca, cb, cc, accumulate);
   return (int)hipGetLastError();
 }
@@ -320,18 +351,26 @@ extern "C" int dtfa_bn_bwd_finalize(const float* part, int R, int C, float count
 // ----------------------------------------------------------------------------
 // dy = ca*g + cb*y + cc,  g = dz * mask ; optionally dres = g.
 // ----------------------------------------------------------------------------
-template <bool RELU, bool DRES>
+template <int RELU, bool DRES>
 __global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ y,
                                     const bf16* __restrict__ zout, bf16* __restrict__ dy, bf16* __restrict__ dres,
                                     const float* __restrict__ ca, const float* __restrict__ cb,
-                                    const float* __restrict__ cc, size_t nvec, int C) {
+                                    const float* __restrict__ cc, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, size_t nvec, int C) {
   const int cvec = C >> 3;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
     int c0 = (int)(i % cvec) << 3;
     bf16x8 g8 = *(const bf16x8*)(dz + i * 8);
     bf16x8 y8 = *(const bf16x8*)(y + i * 8);
     bf16x8 z8;
-    if (RELU) z8 = *(const bf16x8*)(zout + i * 8);
+    if (RELU == 1) z8 = *(const bf16x8*)(zout + i * 8);
+    float S[8], H[8];
+    if (RELU == 2) {
+      float4 s0 = *(const float4*)(scale + c0), s1 = *(const float4*)(scale + c0 + 4);
+      float4 h0 = *(const float4*)(shift + c0), h1 = *(const float4*)(shift + c0 + 4);
+      S[0] = s0.x; S[1] = s0.y; S[2] = s0.z; S[3] = s0.w; S[4] = s1.x; S[5] = s1.y; S[6] = s1.z; S[7] = s1.w;
+      H[0] = h0.x; H[1] = h0.y; H[2] = h0.z; H[3] = h0.w; H[4] = h1.x; H[5] = h1.y; H[6] = h1.z; H[7] = h1.w;
+    }
     float4 a0 = *(const float4*)(ca + c0), a1 = *(const float4*)(ca + c0 + 4);
     float4 b0 = *(const float4*)(cb + c0), b1 = *(const float4*)(cb + c0 + 4);
     float4 d0 = *(const float4*)(cc + c0), d1 = *(const float4*)(cc + c0 + 4);
@@ -342,7 +381,8 @@ __global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float g = (float)g8[j];
-      if (RELU && !((float)z8[j] > 0.f)) g = 0.f;
+      if (RELU == 1 && !((float)z8[j] > 0.f)) g = 0.f;
+      if (RELU == 2 && !((float)y8[j] * S[j] + H[j] > 0.f)) g = 0.f;
       o[j] = (bf16)(A[j] * g + Bc[j] * (float)y8[j] + Cc[j]);
       if (DRES) r[j] = (bf16)g;
     }
@@ -352,20 +392,23 @@ __global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __r
 }
 
 extern "C" int dtfa_bn_bwd_apply(const void* dz, const void* y, const void* zout, void* dy, void* dres,
-                                 const float* ca, const float* cb, const float* cc, long long M, int C, int relu,
-                                 hipStream_t st) {
+                                 const float* ca, const float* cb, const float* cc, const float* scale,
+                                 const float* shift, long long M, int C, int relu, hipStream_t st) {
   if (C % 8) return -1;
+  if ((relu == 1 && !zout) || (relu == 2 && (!scale || !shift))) return -2;
   size_t nvec = (size_t)M * C / 8;
   if (nvec == 0) return 0;
   unsigned blocks = (unsigned)((nvec + 255) / 256);
   if (blocks > 8192) blocks = 8192;
 #define L(R_, D_)                                                                                            \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<R_, D_>), dim3(blocks), dim3(256), 0, st, (const bf16*)dz,         \
-                     (const bf16*)y, (const bf16*)zout, (bf16*)dy, (bf16*)dres, ca, cb, cc, nvec, C)
-  if (relu && dres) L(true, true);
-  else if (relu) L(true, false);
-  else if (dres) L(false, true);
-  else L(false, false);
+                     (const bf16*)y, (const bf16*)zout, (bf16*)dy, (bf16*)dres, ca, cb, cc, scale, shift, nvec, C)
+  if (relu == 1 && dres) L(1, true);
+  else if (relu == 1) L(1, false);
+  else if (relu == 2 && dres) L(2, true);
+  else if (relu == 2) L(2, false);
+  else if (dres) L(0, true);
+  else L(0, false);
 #undef L
   return (int)hipGetLastError();
 }

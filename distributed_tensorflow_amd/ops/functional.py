@@ -108,18 +108,21 @@ class _ConvBnActFn(Function):
         ctx.has_res = residual is not None
         ctx.params = params  # (weight_param, gamma_param, beta_param) python objects
         if need_grad:
-            ctx.save_for_backward(x, weight, y, z if relu else None, gamma, mean, invstd, scale)
+            # the ReLU mask is recomputed from y when nothing was added before the activation
+            keep_z = relu and (residual is not None or not training)
+            ctx.save_for_backward(x, weight, y, z if keep_z else None, gamma, mean, invstd, scale, shift)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, weight, y, z, gamma, mean, invstd, scale = ctx.saved_tensors
+        x, weight, y, z, gamma, mean, invstd, scale, shift = ctx.saved_tensors
         plan = ctx.plan
         wparam, gparam, bparam = ctx.params
         dz = dz.contiguous()
         want_dres = ctx.has_res and ctx.needs_input_grad[4]
         if ctx.training:
-            dy, dres, dgamma, dbeta = K.bn_backward(dz, y, z, mean, invstd, gamma, ctx.relu, want_dres)
+            dy, dres, dgamma, dbeta = K.bn_backward(dz, y, z, mean, invstd, gamma, ctx.relu, want_dres,
+                                                    scale=scale, shift=shift)
         else:
             g = K.relu_bwd(dz, z) if ctx.relu else dz
             dres = g if want_dres else None

@@ -83,10 +83,11 @@ class _Sigs:
     dtfa_bn_apply = [c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_void]
     dtfa_col_partials_rows = [c_ll, c_int]
     dtfa_bn_stats_partials = [c_void, c_void, c_ll, c_int, c_void]
-    dtfa_bn_bwd_partials = [c_void, c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_void]
+    dtfa_bn_bwd_partials = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_void]
     dtfa_bn_bwd_finalize = [c_void, c_int, c_int, c_float, c_void, c_void, c_void, c_void, c_void, c_void, c_void,
                             c_void, c_int, c_void]
-    dtfa_bn_bwd_apply = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_void]
+    dtfa_bn_bwd_apply = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int,
+                         c_void]
     dtfa_relu_bwd = [c_void, c_void, c_void, c_ll, c_void]
     dtfa_add_bf16 = [c_void, c_void, c_void, c_ll, c_void]
     dtfa_maxpool_fwd = [c_void, c_void, c_void, C.POINTER(PoolArgs), c_void]

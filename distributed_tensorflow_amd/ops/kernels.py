@@ -23,7 +23,7 @@ def _as2d(t: torch.Tensor) -> Tuple[int, int]:
 
 
 # ------------------------------------------------------------------ batch norm
-def reduce_partials(part: torch.Tensor, max_rows: int = 128) -> torch.Tensor:
+def reduce_partials(part: torch.Tensor, max_rows: int = 64) -> torch.Tensor:
     """[R][NV][C] -> [RS<=max_rows][NV][C] (fixed summation order)."""
     R, NV, Cc = part.shape
     if R <= max_rows:
@@ -90,24 +90,37 @@ def bn_apply(y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bo
 
 
 def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, dgamma_out=None, dbeta_out=None,
-                accumulate=False):
-    """Returns (dy, dres or None, dgamma, dbeta).  ``zout`` (the activation
-    output) is only read when ``relu``."""
+                accumulate=False, scale=None, shift=None):
+    """Returns (dy, dres or None, dgamma, dbeta).
+
+    With ``relu`` the activation mask is taken from ``zout`` (the stored
+    activation output) when it is given, otherwise it is recomputed from
+    ``y*scale + shift > 0`` (valid when no residual was added), which saves
+    reading one full tensor in each of the two passes."""
     hipk.require(dz, BF16, "dz")
     hipk.require(y, BF16, "y")
     if dz.shape != y.shape:
         raise ValueError("dz/y shape mismatch")
+    mode = 0
     if relu:
-        hipk.require(zout, BF16, "zout")
-        if zout.shape != y.shape:
-            raise ValueError("zout shape mismatch")
+        if zout is not None:
+            hipk.require(zout, BF16, "zout")
+            if zout.shape != y.shape:
+                raise ValueError("zout shape mismatch")
+            mode = 1
+        else:
+            if scale is None or shift is None:
+                raise ValueError("ReLU mask needs either zout or scale/shift")
+            mode = 2
     M, Cc = _as2d(y)
     L = hipk.lib()
     rows = L.dtfa_col_partials_rows(M, Cc)
     part = torch.empty((rows, 2, Cc), dtype=F32, device=y.device)
-    hipk.check(L.dtfa_bn_bwd_partials(dz.data_ptr(), y.data_ptr(), hipk.ptr(zout) if relu else None,
-                                      mean.data_ptr(), invstd.data_ptr(), part.data_ptr(), M, Cc,
-                                      1 if relu else 0, hipk.stream()), "bn_bwd_partials")
+    zp = hipk.ptr(zout) if mode == 1 else None
+    sp = scale.data_ptr() if mode == 2 else None
+    hp = shift.data_ptr() if mode == 2 else None
+    hipk.check(L.dtfa_bn_bwd_partials(dz.data_ptr(), y.data_ptr(), zp, mean.data_ptr(), invstd.data_ptr(), sp, hp,
+                                      part.data_ptr(), M, Cc, mode, hipk.stream()), "bn_bwd_partials")
     part = reduce_partials(part)
     coef = torch.empty((3, Cc), dtype=F32, device=y.device)
     dgamma = dgamma_out if dgamma_out is not None else torch.empty(Cc, dtype=F32, device=y.device)
@@ -119,9 +132,9 @@ def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, d
                                       hipk.stream()), "bn_bwd_finalize")
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
-    hipk.check(L.dtfa_bn_bwd_apply(dz.data_ptr(), y.data_ptr(), hipk.ptr(zout) if relu else None, dy.data_ptr(),
-                                   hipk.ptr(dres), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), M, Cc,
-                                   1 if relu else 0, hipk.stream()), "bn_bwd_apply")
+    hipk.check(L.dtfa_bn_bwd_apply(dz.data_ptr(), y.data_ptr(), zp, dy.data_ptr(), hipk.ptr(dres),
+                                   coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), sp, hp, M, Cc, mode,
+                                   hipk.stream()), "bn_bwd_apply")
     return dy, dres, dgamma, dbeta
 
 
