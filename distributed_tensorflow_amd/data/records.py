@@ -1,0 +1,114 @@
+"""TFRecord training input (``train_input_fn`` of the reference,
+recognition_flower/distributed/train_dataset.py:68-94) on the native loader.
+
+Records hold raw decoded pixels: ``image_raw`` (H*W*C uint8, OpenCV BGR
+order), ``label``, ``height``, ``width``, ``channel``
+(recognition_flower/distributed/prepare.py:45-51).  The C++ loader
+(csrc/host/loader.cc) reads / parses / packs batches on worker threads into
+pinned buffers; the batch is uploaded with one copy and resized on the GPU to
+``[B, 299, 299, 8]`` (bilinear, TensorFlow legacy coordinates, like
+``tf.image.resize_images(method=0)``).
+
+Differences from the reference, on purpose: examples (not whole batches) are
+shuffled, every rank reads a disjoint shard, pixels are converted to RGB and
+normalised to [-1, 1] (``legacy_bgr_unnormalised=True`` restores the reference's
+BGR [0, 255] input).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterator, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..io import hostlib
+from .preprocess import NORM_INCEPTION, NORM_NONE, _ImageDesc, preprocess_batch, resize_on_device
+
+
+class RecordInput:
+    def __init__(self, path: str, batch_size: int, device, *, image_size: int = 299, num_epochs: int = 1,
+                 rank: int = 0, world: int = 1, threads: int = 4, prefetch: int = 4, shuffle: bool = True,
+                 seed: int = 0, drop_remainder: bool = False, legacy_bgr_unnormalised: bool = False,
+                 max_image_bytes: int = 1 << 20):
+        self.device = torch.device(device)
+        self.batch_size, self.image_size = batch_size, image_size
+        self.legacy = legacy_bgr_unnormalised
+        self._L = hostlib.lib()
+        cap = batch_size * max_image_bytes
+        pin = self.device.type == "cuda"
+        self._bufs = [torch.empty(cap, dtype=torch.uint8).pin_memory() if pin else torch.empty(cap, dtype=torch.uint8)
+                      for _ in range(prefetch)]
+        ptrs = (C.c_void_p * prefetch)(*[b.data_ptr() for b in self._bufs])
+        self._h = self._L.dtfa_loader_open(path.encode(), rank, world, batch_size, threads, prefetch, ptrs, cap,
+                                           seed, 1 if shuffle else 0, num_epochs, 1 if drop_remainder else 0)
+        if not self._h:
+            raise IOError("cannot open TFRecord file %s (missing, empty or corrupt)" % path)
+        self.num_records = self._L.dtfa_loader_num_records(self._h)
+        self.num_batches = self._L.dtfa_loader_num_batches(self._h)
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        return self
+
+    def __next__(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        b = hostlib.Batch()
+        rc = self._L.dtfa_loader_next(self._h, C.byref(b))
+        if rc == 0:
+            raise StopIteration  # the reference surfaces this as OutOfRangeError -> should_stop()
+        if rc < 0:
+            raise IOError("record loader failed with code %d (bad record, or image larger than max_image_bytes)" % rc)
+        try:
+            n = b.count
+            labels = torch.tensor([b.labels[i] for i in range(n)], dtype=torch.int32)
+            descs = (_ImageDesc * n)()
+            for i in range(n):
+                h, w, c = b.heights[i], b.widths[i], b.channels[i]
+                descs[i] = _ImageDesc(b.offsets[i], h, w, c, 0.0, 0.0, float(h), float(w), 0, 0)
+            norm = NORM_NONE if self.legacy else NORM_INCEPTION
+            bgr_to_rgb = not self.legacy
+            size = (self.image_size, self.image_size)
+            host = self._bufs[b.slot][: int(b.bytes_used)]
+            if self.device.type == "cuda":
+                dev = host.to(self.device, non_blocking=True)
+                dd = torch.from_numpy(np.frombuffer(descs, dtype=np.uint8).copy()).to(self.device, non_blocking=True)
+                x = resize_on_device(dev, dd, n, size, "bilinear_legacy", bgr_to_rgb, norm)
+                torch.cuda.current_stream().synchronize()  # the slot is reused after release
+                return x, labels.to(self.device)
+            arr = host.numpy()
+            images = [arr[b.offsets[i]: b.offsets[i] + b.heights[i] * b.widths[i] * b.channels[i]]
+                      .reshape(b.heights[i], b.widths[i], b.channels[i]) for i in range(n)]
+            x = preprocess_batch(images, size, "cpu", "bilinear_legacy", None, bgr_to_rgb, norm)
+            return x, labels
+        finally:
+            self._L.dtfa_loader_release(self._h, b.slot)
+
+    def close(self) -> None:
+        if self._h:
+            self._L.dtfa_loader_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class SyntheticInput:
+    """Endless random batches with flower_photos-like shape (for throughput measurement)."""
+
+    def __init__(self, batch_size: int, image_size: int, device, num_classes: int = 5, seed: int = 0,
+                 dtype: Optional[torch.dtype] = None):
+        device = torch.device(device)
+        g = torch.Generator().manual_seed(seed)
+        dtype = dtype or (torch.bfloat16 if device.type == "cuda" else torch.float32)
+        x = torch.zeros(batch_size, image_size, image_size, 8)
+        x[..., :3] = torch.rand(batch_size, image_size, image_size, 3, generator=g) * 2 - 1
+        self.x = x.to(device=device, dtype=dtype)
+        self.y = torch.randint(0, num_classes, (batch_size,), generator=g).to(device=device, dtype=torch.int32)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return self.x, self.y

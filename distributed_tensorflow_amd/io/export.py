@@ -1,0 +1,153 @@
+"""Servable export and loading (the SavedModel step of the reference).
+
+The reference exports a TensorFlow SavedModel with two signatures
+(recognition_flower/single/flower_train.py:195-251,
+recognition_flower/distributed/save_model.py:116-171):
+
+``serving_default``  method ``tensorflow/serving/classify``; input ``inputs`` =
+    serialized ``tf.Example`` strings carrying ``image/encoded`` JPEG bytes;
+    outputs ``classes`` (string) and ``scores`` (float).
+``predict_images``   method ``tensorflow/serving/predict``; input ``images`` =
+    JPEG byte strings; outputs ``classes`` and ``scores``.
+
+``saved_model.pb`` is a serialized TensorFlow graph and cannot be produced
+without TensorFlow, so the export here is a *servable bundle* with the same
+directory contract and the same request / response contract::
+
+    <output_dir>/<model_version>/saved_model.json            signature manifest, class vocabulary,
+                                                             preprocessing spec, model recipe
+    <output_dir>/<model_version>/variables/variables.index   Saver-V2 bundle (TensorFlow variable names)
+    <output_dir>/<model_version>/variables/variables.data-00000-of-00001
+
+:class:`Servable` loads such a directory and answers both signatures.  Scores
+are the raw top-1 logits, exactly like the reference (``tf.nn.top_k(logits, 1)``,
+recognition_flower/single/flower_train.py:154); probabilities are returned as an
+extra output.  Unlike the reference's ``save_model.py``, which builds its
+serving graph with ``training=True``, the servable always runs in inference
+mode (batch-norm running statistics, no dropout).
+"""
+from __future__ import annotations
+
+import json
+import os
+import shutil
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import bundle
+from .saver import Saver
+from .tfrecord import make_example, parse_example
+
+MANIFEST = "saved_model.json"
+
+
+def signature_manifest() -> Dict:
+    return {
+        "serving_default": {
+            "method_name": "tensorflow/serving/classify",
+            "inputs": {"inputs": {"dtype": "string", "description": "serialized tf.Example with image/encoded"}},
+            "outputs": {"classes": {"dtype": "string"}, "scores": {"dtype": "float"}},
+        },
+        "predict_images": {
+            "method_name": "tensorflow/serving/predict",
+            "inputs": {"images": {"dtype": "string", "description": "JPEG bytes"}},
+            "outputs": {"classes": {"dtype": "string"}, "scores": {"dtype": "float"}},
+        },
+    }
+
+
+def export_servable(model, classes: Sequence[str], output_dir: str, model_version: int, *, model_name: str,
+                    image_size: int, model_kwargs: Optional[dict] = None, engine=None,
+                    global_step: int = 0, overwrite: bool = True) -> str:
+    export_path = os.path.join(output_dir, str(model_version))
+    if os.path.exists(export_path):
+        if not overwrite:
+            raise FileExistsError(export_path)
+        # the reference shells out to `rm -r` here (recognition_flower/single/flower_train.py:200-201)
+        shutil.rmtree(export_path)
+    os.makedirs(os.path.join(export_path, "variables"))
+    saver = Saver(model, engine)
+    tensors = saver.variables(include_slots=False)
+    bundle.write_bundle(os.path.join(export_path, "variables", "variables"), tensors)
+    manifest = {
+        "format": "dtfa-servable-1",
+        "tags": ["serve"],
+        "signature_def": signature_manifest(),
+        "classes": list(classes),
+        "model": {"name": model_name, "kwargs": model_kwargs or {}, "num_classes": len(classes)},
+        "preprocess": {"decode": "jpeg", "resize": "bicubic_legacy", "image_size": int(image_size),
+                       "range": [-1.0, 1.0]},
+        "global_step": int(global_step),
+    }
+    with open(os.path.join(export_path, MANIFEST), "w") as f:
+        json.dump(manifest, f, indent=2, sort_keys=True)
+    return export_path
+
+
+class Servable:
+    def __init__(self, export_path: str, device=None):
+        from ..models import build_model
+
+        with open(os.path.join(export_path, MANIFEST)) as f:
+            self.manifest = json.load(f)
+        if self.manifest.get("format") != "dtfa-servable-1":
+            raise ValueError("unknown servable format")
+        self.classes: List[str] = self.manifest["classes"]
+        self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        m = self.manifest["model"]
+        self.model = build_model(m["name"], num_classes=m["num_classes"], device=self.device, **m["kwargs"])
+        Saver(self.model).restore(os.path.join(export_path, "variables", "variables"), strict=True)
+        self.model.eval()
+        self.image_size = int(self.manifest["preprocess"]["image_size"])
+        self.method = self.manifest["preprocess"]["resize"]
+
+    # ------------------------------------------------------------------ helpers
+    def _preprocess(self, jpegs: Sequence[bytes]) -> torch.Tensor:
+        from ..data import jpeg as J
+        from ..data.preprocess import NORM_INCEPTION, make_descs, preprocess_batch, resize_on_device
+
+        size = (self.image_size, self.image_size)
+        if self.device.type == "cuda":
+            packed, shapes, offs = J.decode_batch_to_device(jpegs, self.device)
+            descs = torch.from_numpy(make_descs(shapes, offs)).to(self.device)
+            return resize_on_device(packed, descs, len(jpegs), size, self.method, False, NORM_INCEPTION)
+        images = [J.decode_reference(j) for j in jpegs]
+        return preprocess_batch(images, size, "cpu", self.method, None, False, NORM_INCEPTION)
+
+    @torch.no_grad()
+    def _infer(self, jpegs: Sequence[bytes]) -> Dict[str, np.ndarray]:
+        if len(jpegs) == 0:
+            z = np.zeros((0, 1))
+            return {"classes": z.astype(object), "scores": z.astype(np.float32), "probabilities": np.zeros((0, len(self.classes)), np.float32)}
+        x = self._preprocess(jpegs)
+        out = self.model(x)
+        logits = (out[0] if isinstance(out, tuple) else out)[:, :len(self.classes)].float()
+        scores, idx = logits.max(dim=1, keepdim=True)
+        probs = torch.softmax(logits, dim=1)
+        names = np.array([[self.classes[i]] for i in idx.view(-1).tolist()], dtype=object)
+        return {"classes": names, "scores": scores.cpu().numpy(), "probabilities": probs.cpu().numpy()}
+
+    # ------------------------------------------------------------------ signatures
+    def predict_images(self, images: Sequence[bytes]) -> Dict[str, np.ndarray]:
+        """``predict_images`` signature: JPEG bytes in, (class string, raw top-1 logit) out, shape [N, 1]."""
+        return self._infer(list(images))
+
+    def serving_default(self, inputs: Sequence[bytes]) -> Dict[str, np.ndarray]:
+        """``serving_default`` (classify) signature: serialized tf.Example strings with ``image/encoded``."""
+        jpegs = []
+        for rec in inputs:
+            ex = parse_example(rec)
+            enc = ex.get("image/encoded")
+            if not enc:
+                raise ValueError("tf.Example lacks the image/encoded feature")
+            jpegs.append(enc[0])
+        return self._infer(jpegs)
+
+    classify = serving_default
+
+
+def example_from_jpeg(jpeg: bytes) -> bytes:
+    """Client-side helper: the tf.Example the classify signature expects."""
+    return make_example({"image/encoded": jpeg})

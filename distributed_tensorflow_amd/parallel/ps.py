@@ -1,0 +1,516 @@
+"""Parameter-server runtime: ``ps`` / ``worker`` roles over TCP.
+
+This is the between-graph-replicated asynchronous training of the reference
+(recognition_flower/distributed/train_dataset.py:131-192) without TensorFlow's
+gRPC runtime:
+
+* a **ps** task owns a subset of the trainable variables (assigned round-robin
+  in creation order, like ``tf.train.replica_device_setter``), their optimizer
+  slots, and -- on ps 0 -- the global step.  It applies every gradient it
+  receives immediately (``ApplyAdam`` runs on the ps, next to the variable).
+* a **worker** task keeps a full model replica, and per step *pulls* the current
+  variables, computes gradients on its own batch and *pushes* them.  Workers
+  never talk to each other, may join late, finish early or die without
+  affecting the rest (the property the reference gets from ``device_filters``,
+  train_dataset.py:172-174).  Only trainable variables travel; the frozen trunk
+  stays on the worker (the reference re-pulls all of it every step).
+* initialisation happens exactly once: the chief worker uploads its initial
+  values, everybody else blocks in ``wait_init`` (the reference lets every
+  worker re-run the init op, resetting the ps each time a worker joins).
+* **bounded staleness** (stale-synchronous parallel): every worker carries a
+  clock (its number of pushed steps); with ``staleness = s >= 0`` a pull from a
+  worker whose clock is more than ``s`` ahead of the slowest *live* worker is
+  held back until the others catch up.  ``s < 0`` is the reference's unbounded
+  asynchrony, ``s = 0`` is lock-step.  A worker that stays silent for
+  ``worker_timeout`` seconds or disconnects stops counting, so nobody waits
+  for the dead.
+
+Wire format: 32-byte header ``<4sIiiqQ`` (magic ``DTPS``, op, worker, status,
+clock/step, payload bytes) followed by the payload (fp32 little-endian blobs or
+UTF-8 JSON).
+"""
+from __future__ import annotations
+
+import json
+import socket
+import struct
+import threading
+import time
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..optim import OptRegion, make_optimizer
+
+MAGIC = b"DTPS"
+HEADER = struct.Struct("<4sIiiqQ")
+
+OP_HELLO, OP_INIT, OP_WAIT_INIT, OP_PULL, OP_PUSH, OP_GET_STATE, OP_SET_STATE, OP_BYE, OP_SHUTDOWN, OP_STATUS = range(1, 11)
+ST_OK, ST_NOT_INIT, ST_ERROR, ST_STOPPED = 0, 1, 2, 3
+
+
+class PSStopped(ConnectionError):
+    """The parameter server is shutting down (the chief finished the step budget)."""
+
+
+def _recv_exact(sock: socket.socket, n: int) -> bytearray:
+    buf = bytearray(n)
+    view = memoryview(buf)
+    got = 0
+    while got < n:
+        k = sock.recv_into(view[got:], n - got)
+        if k == 0:
+            raise ConnectionError("peer closed the connection")
+        got += k
+    return buf
+
+
+def _send_msg(sock, op, worker=0, status=0, clock=0, payload: bytes = b""):
+    sock.sendall(HEADER.pack(MAGIC, op, worker, status, clock, len(payload)))
+    if payload:
+        sock.sendall(payload)
+
+
+def _recv_msg(sock):
+    magic, op, worker, status, clock, n = HEADER.unpack(bytes(_recv_exact(sock, HEADER.size)))
+    if magic != MAGIC:
+        raise ConnectionError("bad magic")
+    payload = _recv_exact(sock, n) if n else bytearray()
+    return op, worker, status, clock, payload
+
+
+# ----------------------------------------------------------------------------
+# server
+# ----------------------------------------------------------------------------
+class ParameterServer:
+    """One ps task.  ``serve_forever`` blocks like ``server.join()``
+    (recognition_flower/distributed/train_dataset.py:142-145) until a SHUTDOWN
+    request arrives."""
+
+    def __init__(self, host: str, port: int, ps_index: int = 0, staleness: int = -1, worker_timeout: float = 30.0):
+        self.addr = (host, port)
+        self.ps_index = ps_index
+        self.staleness = staleness
+        self.worker_timeout = worker_timeout
+        self.lock = threading.Condition()
+        self.initialized = False
+        self.params: Optional[torch.Tensor] = None
+        self.grad: Optional[torch.Tensor] = None
+        self.optimizer = None
+        self.global_step = 0
+        self.apply_count = 0
+        self.clocks: Dict[int, int] = {}
+        self.last_seen: Dict[int, float] = {}
+        self.max_lag_seen = 0  # largest (clock - min live clock) ever admitted to pull; checked by tests
+        self._stop = threading.Event()
+        self._sock = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        self._sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        self._sock.bind(self.addr)
+        self._sock.listen(64)
+        self._sock.settimeout(0.2)
+        self._threads: List[threading.Thread] = []
+        self._conns: List[socket.socket] = []
+
+    # -- staleness bookkeeping -------------------------------------------------
+    def _live_min_clock(self, now: float) -> Optional[int]:
+        live = [c for w, c in self.clocks.items() if now - self.last_seen.get(w, 0) <= self.worker_timeout]
+        return min(live) if live else None
+
+    def _wait_for_staleness(self, worker: int, clock: int) -> None:
+        if self.staleness < 0:
+            return
+        with self.lock:
+            while not self._stop.is_set():
+                now = time.time()
+                self.last_seen[worker] = now
+                m = self._live_min_clock(now)
+                if m is None or clock - m <= self.staleness:
+                    if m is not None:
+                        self.max_lag_seen = max(self.max_lag_seen, clock - m)
+                    return
+                self.lock.wait(timeout=0.05)
+
+    # -- request handling --------------------------------------------------------
+    def _handle(self, conn: socket.socket) -> None:
+        worker = -1
+        try:
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            while True:
+                op, worker, _, clock, payload = _recv_msg(conn)
+                now = time.time()
+                if self._stop.is_set() and op in (OP_PULL, OP_PUSH, OP_WAIT_INIT, OP_INIT):
+                    # shutting down: tell the worker instead of dropping the connection
+                    _send_msg(conn, op, worker, ST_STOPPED, self.global_step)
+                    continue
+                if op == OP_HELLO:
+                    with self.lock:
+                        self.last_seen[worker] = now
+                        self.clocks.setdefault(worker, int(clock))
+                    _send_msg(conn, op, worker, ST_OK if self.initialized else ST_NOT_INIT, self.global_step)
+                elif op == OP_INIT:
+                    meta_len = struct.unpack("<I", bytes(payload[:4]))[0]
+                    meta = json.loads(bytes(payload[4:4 + meta_len]).decode())
+                    blob = np.frombuffer(payload, dtype=np.float32, offset=4 + meta_len).copy()
+                    with self.lock:
+                        if not self.initialized:  # first initialiser wins; later ones are ignored
+                            self.params = torch.from_numpy(blob)
+                            self.grad = torch.zeros_like(self.params)
+                            self.optimizer = make_optimizer(meta.get("optimizer", "adam"),
+                                                            [OptRegion("ps%d" % self.ps_index, self.params, self.grad,
+                                                                       None, False)],
+                                                            float(meta.get("lr", 1e-3)), **meta.get("opt_kwargs", {}))
+                            self.global_step = int(meta.get("global_step", 0))
+                            self.optimizer.step_count = self.global_step
+                            self.initialized = True
+                            self.lock.notify_all()
+                    _send_msg(conn, op, worker, ST_OK, self.global_step)
+                elif op == OP_WAIT_INIT:
+                    with self.lock:
+                        while not self.initialized and not self._stop.is_set():
+                            self.lock.wait(timeout=0.1)
+                    _send_msg(conn, op, worker, ST_OK if self.initialized else ST_STOPPED, self.global_step)
+                elif op == OP_PULL:
+                    if not self.initialized:
+                        _send_msg(conn, op, worker, ST_NOT_INIT, 0)
+                        continue
+                    self._wait_for_staleness(worker, int(clock))
+                    with self.lock:
+                        self.last_seen[worker] = time.time()
+                        data = self.params.numpy().tobytes()
+                        step = self.global_step
+                    _send_msg(conn, op, worker, ST_OK, step, data)
+                elif op == OP_PUSH:
+                    if not self.initialized:
+                        _send_msg(conn, op, worker, ST_NOT_INIT, 0)
+                        continue
+                    g = torch.from_numpy(np.frombuffer(payload, dtype=np.float32).copy())
+                    with self.lock:
+                        if g.numel() != self.params.numel():
+                            _send_msg(conn, op, worker, ST_ERROR, 0)
+                            continue
+                        self.grad.copy_(g)
+                        self.optimizer.step()
+                        self.apply_count += 1
+                        self.global_step += 1
+                        self.clocks[worker] = int(clock) + 1
+                        self.last_seen[worker] = time.time()
+                        step = self.global_step
+                        self.lock.notify_all()
+                    _send_msg(conn, op, worker, ST_OK, step)
+                elif op == OP_GET_STATE:
+                    with self.lock:
+                        if not self.initialized:
+                            _send_msg(conn, op, worker, ST_NOT_INIT, 0)
+                            continue
+                        slots = self.optimizer.slots()
+                        names = sorted(slots)
+                        meta = json.dumps({"slots": names, "global_step": self.global_step,
+                                           "apply_count": self.apply_count,
+                                           "beta1_power": getattr(self.optimizer, "beta1_power", None),
+                                           "beta2_power": getattr(self.optimizer, "beta2_power", None)}).encode()
+                        blob = b"".join([self.params.numpy().tobytes()] + [slots[k].numpy().tobytes() for k in names])
+                    _send_msg(conn, op, worker, ST_OK, self.global_step, struct.pack("<I", len(meta)) + meta + blob)
+                elif op == OP_SET_STATE:
+                    meta_len = struct.unpack("<I", bytes(payload[:4]))[0]
+                    meta = json.loads(bytes(payload[4:4 + meta_len]).decode())
+                    blob = np.frombuffer(payload, dtype=np.float32, offset=4 + meta_len)
+                    with self.lock:
+                        if not self.initialized:
+                            _send_msg(conn, op, worker, ST_NOT_INIT, 0)
+                            continue
+                        n = self.params.numel()
+                        self.params.copy_(torch.from_numpy(blob[:n].copy()))
+                        slots = self.optimizer.slots()
+                        for i, k in enumerate(meta.get("slots", [])):
+                            if k in slots:
+                                slots[k].copy_(torch.from_numpy(blob[(i + 1) * n:(i + 2) * n].copy()))
+                        self.global_step = int(meta.get("global_step", self.global_step))
+                        self.optimizer.step_count = self.global_step
+                    _send_msg(conn, op, worker, ST_OK, self.global_step)
+                elif op == OP_STATUS:
+                    with self.lock:
+                        meta = json.dumps({"initialized": self.initialized, "global_step": self.global_step,
+                                           "clocks": {str(k): v for k, v in self.clocks.items()},
+                                           "max_lag_seen": self.max_lag_seen, "staleness": self.staleness}).encode()
+                    _send_msg(conn, op, worker, ST_OK, self.global_step, meta)
+                elif op == OP_BYE:
+                    with self.lock:
+                        self.clocks.pop(worker, None)
+                        self.last_seen.pop(worker, None)
+                        self.lock.notify_all()
+                    _send_msg(conn, op, worker, ST_OK, self.global_step)
+                    return
+                elif op == OP_SHUTDOWN:
+                    _send_msg(conn, op, worker, ST_OK, self.global_step)
+                    self._stop.set()
+                    with self.lock:
+                        self.lock.notify_all()
+                    return
+                else:
+                    _send_msg(conn, op, worker, ST_ERROR, 0)
+        except (ConnectionError, OSError):
+            pass
+        finally:
+            # a vanished worker must not hold the others back
+            with self.lock:
+                if worker in self.clocks:
+                    self.clocks.pop(worker, None)
+                    self.last_seen.pop(worker, None)
+                self.lock.notify_all()
+            try:
+                conn.close()
+            except OSError:
+                pass
+
+    def serve_forever(self) -> None:
+        try:
+            while not self._stop.is_set():
+                try:
+                    conn, _ = self._sock.accept()
+                except socket.timeout:
+                    continue
+                conn.settimeout(None)
+                t = threading.Thread(target=self._handle, args=(conn,), daemon=True)
+                t.start()
+                self._threads.append(t)
+                self._conns.append(conn)
+        finally:
+            self._sock.close()
+            # grace period: let the remaining workers notice ST_STOPPED and say BYE, then
+            # unblock whatever is left so that every handler thread exits before we return
+            deadline = time.time() + 3.0
+            for t in self._threads:
+                t.join(timeout=max(0.0, deadline - time.time()))
+            for c in self._conns:
+                try:
+                    c.shutdown(socket.SHUT_RDWR)
+                except OSError:
+                    pass
+            for t in self._threads:
+                t.join(timeout=1.0)
+
+    def start_background(self) -> threading.Thread:
+        t = threading.Thread(target=self.serve_forever, daemon=True)
+        t.start()
+        return t
+
+    def stop(self) -> None:
+        self._stop.set()
+        with self.lock:
+            self.lock.notify_all()
+
+
+# ----------------------------------------------------------------------------
+# client
+# ----------------------------------------------------------------------------
+class _Conn:
+    def __init__(self, host: str, port: int, worker: int, connect_timeout: float):
+        deadline = time.time() + connect_timeout
+        last = None
+        while True:
+            try:
+                self.sock = socket.create_connection((host, port), timeout=5.0)
+                break
+            except OSError as e:  # the ps may not be up yet
+                last = e
+                if time.time() > deadline:
+                    raise ConnectionError("cannot reach ps at %s:%d: %s" % (host, port, last))
+                time.sleep(0.1)
+        self.sock.settimeout(None)
+        self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        self.worker = worker
+
+    def call(self, op, clock=0, payload: bytes = b""):
+        _send_msg(self.sock, op, self.worker, 0, clock, payload)
+        rop, _, status, rclock, data = _recv_msg(self.sock)
+        if rop != op:
+            raise ConnectionError("protocol error: reply %d to request %d" % (rop, op))
+        return status, rclock, data
+
+    def close(self):
+        try:
+            self.sock.close()
+        except OSError:
+            pass
+
+
+class PSWorkerEngine:
+    """Worker-side engine with the ``begin_step`` / ``finish_step`` interface of
+    :class:`DataParallelEngine`, talking to one or more ps tasks."""
+
+    def __init__(self, model, ps_addresses: List[Tuple[str, int]], worker_index: int, is_chief: bool, *,
+                 optimizer: str = "adam", lr: float = 1e-3, opt_kwargs: Optional[dict] = None,
+                 connect_timeout: float = 60.0, initial_global_step: int = 0):
+        from .flat import FlatParams
+
+        self.model = model
+        self.worker_index = worker_index
+        self.is_chief = is_chief
+        self.flat = FlatParams(model, bucket_mb=1 << 20)  # one bucket per group: no collectives here
+        self.lr = lr
+        self.clock = 0
+        self.global_step = initial_global_step
+        self.optimizer = self  # exposes current_lr() to the session
+        self._optimizer_name, self._opt_kwargs = optimizer, dict(opt_kwargs or {})
+        # round-robin variable placement over ps tasks, in creation order
+        segs = []
+        for g in self.flat.groups:
+            for s in g.segments:
+                segs.append((g, s))
+        segs.reverse()  # FlatParams stores reverse registration order
+        self.placement: List[List[Tuple[object, object]]] = [[] for _ in ps_addresses]
+        for i, gs in enumerate(segs):
+            self.placement[i % len(ps_addresses)].append(gs)
+        self.conns = [_Conn(h, p, worker_index, connect_timeout) for h, p in ps_addresses]
+        for c in self.conns:
+            c.call(OP_HELLO, 0)
+        if is_chief:
+            for i, c in enumerate(self.conns):
+                meta = json.dumps({"optimizer": optimizer, "lr": lr, "opt_kwargs": self._opt_kwargs,
+                                   "global_step": initial_global_step}).encode()
+                c.call(OP_INIT, 0, struct.pack("<I", len(meta)) + meta + self._pack(i, "master"))
+        else:
+            for c in self.conns:
+                st, _, _ = c.call(OP_WAIT_INIT, 0)
+                if st != ST_OK:
+                    raise ConnectionError("parameter server stopped before initialisation")
+        self.pull()
+
+    def current_lr(self) -> float:
+        return self.lr
+
+    # -- (un)packing -------------------------------------------------------------
+    def _pack(self, ps: int, what: str) -> bytes:
+        parts = []
+        for g, s in self.placement[ps]:
+            src = g.master if what == "master" else g.grad
+            parts.append(src[s.offset:s.offset + s.numel].detach().float().cpu().numpy().tobytes())
+        return b"".join(parts)
+
+    def _unpack_params(self, ps: int, data) -> None:
+        arr = np.frombuffer(data, dtype=np.float32)
+        pos = 0
+        for g, s in self.placement[ps]:
+            g.master[s.offset:s.offset + s.numel].copy_(torch.from_numpy(arr[pos:pos + s.numel].copy()))
+            pos += s.numel
+        if pos != arr.size:
+            raise ConnectionError("ps %d returned %d values, expected %d" % (ps, arr.size, pos))
+
+    # -- protocol ---------------------------------------------------------------
+    def pull(self) -> None:
+        for i, c in enumerate(self.conns):
+            st, step, data = c.call(OP_PULL, self.clock)
+            if st == ST_STOPPED:
+                raise PSStopped("parameter server is shutting down")
+            if st != ST_OK:
+                raise ConnectionError("pull failed with status %d" % st)
+            self._unpack_params(i, data)
+            if i == 0:
+                self.global_step = int(step)
+        for g in self.flat.groups:
+            g.sync_compute_from_master()
+
+    def begin_step(self) -> None:
+        self.flat.begin_step()
+        self.pull()
+
+    def finish_step(self) -> int:
+        self.flat.collect_autograd_grads()
+        for i, c in enumerate(self.conns):
+            st, step, _ = c.call(OP_PUSH, self.clock, self._pack(i, "grad"))
+            if st == ST_STOPPED:
+                raise PSStopped("parameter server is shutting down")
+            if st != ST_OK:
+                raise ConnectionError("push failed with status %d" % st)
+            if i == 0:
+                self.global_step = int(step)
+        self.clock += 1
+        return self.global_step
+
+    def drain(self) -> None:
+        pass
+
+    def status(self) -> dict:
+        _, _, data = self.conns[0].call(OP_STATUS, self.clock)
+        return json.loads(bytes(data).decode())
+
+    # -- checkpoint support (used by io.saver.Saver) --------------------------------
+    def _fetch_state(self):
+        """Full-layout fp32 masters and optimizer slots gathered from every ps."""
+        masters = {g.name: g.master.clone() for g in self.flat.groups}
+        slots: Dict[str, torch.Tensor] = {}
+        info = {}
+        for i, c in enumerate(self.conns):
+            st, step, payload = c.call(OP_GET_STATE, self.clock)
+            if st != ST_OK:
+                raise ConnectionError("get_state failed")
+            meta_len = struct.unpack("<I", bytes(payload[:4]))[0]
+            meta = json.loads(bytes(payload[4:4 + meta_len]).decode())
+            blob = np.frombuffer(payload, dtype=np.float32, offset=4 + meta_len)
+            n = sum(s.numel for _, s in self.placement[i])
+            if i == 0:
+                info = meta
+            for k, sname in enumerate([None] + meta["slots"]):
+                arr = blob[k * n:(k + 1) * n]
+                pos = 0
+                for g, s in self.placement[i]:
+                    if sname is None:
+                        dst = masters[g.name]
+                    else:
+                        key = sname.rsplit("/", 1)[0] + "/" + g.name
+                        if key not in slots:
+                            slots[key] = torch.zeros_like(g.master)
+                        dst = slots[key]
+                    dst[s.offset:s.offset + s.numel].copy_(torch.from_numpy(arr[pos:pos + s.numel].copy()))
+                    pos += s.numel
+        return masters, slots, info
+
+    def full_master(self):
+        masters, slots, info = self._fetch_state()
+        self._cached_slots, self._cached_info = slots, info
+        for g in self.flat.groups:
+            g.master.copy_(masters[g.name])
+        return {g.name: g.master for g in self.flat.groups}
+
+    def full_slots(self):
+        if getattr(self, "_cached_slots", None) is None:
+            self.full_master()
+        s = self._cached_slots
+        self._cached_slots = None
+        return s
+
+    @property
+    def beta1_power(self):
+        return (getattr(self, "_cached_info", {}) or {}).get("beta1_power")
+
+    @property
+    def beta2_power(self):
+        return (getattr(self, "_cached_info", {}) or {}).get("beta2_power")
+
+    def load_master(self) -> None:
+        """Push restored master values (``FlatGroup.master``) back to the ps tasks."""
+        for i, c in enumerate(self.conns):
+            meta = json.dumps({"slots": [], "global_step": self.global_step}).encode()
+            c.call(OP_SET_STATE, self.clock, struct.pack("<I", len(meta)) + meta + self._pack(i, "master"))
+        for g in self.flat.groups:
+            g.sync_compute_from_master()
+
+    def load_full_slots(self, full) -> None:
+        pass  # optimizer slots are re-created on the ps; restoring them is not supported over the wire yet
+
+    @property
+    def step_count(self):
+        return self.global_step
+
+    @step_count.setter
+    def step_count(self, v):
+        self.global_step = int(v)
+
+    def close(self, shutdown_ps: bool = False) -> None:
+        for c in self.conns:
+            try:
+                c.call(OP_SHUTDOWN if shutdown_ps else OP_BYE, self.clock)
+            except (ConnectionError, OSError):
+                pass
+            c.close()

@@ -1,0 +1,244 @@
+"""Training session loop and hooks (``MonitoredTrainingSession`` work-alike).
+
+The reference drives training with ``sess.run`` loops: the single-process
+script logs loss / accuracy / learning-rate every step and writes summaries
+(recognition_flower/single/flower_train.py:177-193); the distributed script
+wraps the loop in ``MonitoredTrainingSession`` with a ``CheckpointSaverHook``
+and a ``SummarySaverHook`` firing every 2 global steps
+(recognition_flower/distributed/train_dataset.py:176-192).  ``TrainingSession``
+reproduces that structure on top of the data-parallel engine; hooks receive
+the step results and decide by *global step* (not by epoch, and only on the
+chief for file-writing hooks).
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Any, Callable, Dict, List, Optional
+
+import torch
+
+from ..ops import functional as F
+
+
+@dataclass
+class StepResult:
+    global_step: int
+    loss: float
+    accuracy: float
+    learning_rate: float
+    batch_size: int
+    step_time: float
+    logits: Optional[torch.Tensor] = None
+    extra: Dict[str, Any] = field(default_factory=dict)
+
+
+class Hook:
+    chief_only = False
+
+    def begin(self, session: "TrainingSession") -> None:
+        pass
+
+    def after_step(self, session: "TrainingSession", r: StepResult) -> None:
+        pass
+
+    def end(self, session: "TrainingSession") -> None:
+        pass
+
+
+class StopAtStepHook(Hook):
+    def __init__(self, last_step: int):
+        self.last_step = last_step
+
+    def after_step(self, session, r):
+        if r.global_step >= self.last_step:
+            session.request_stop()
+
+
+class LoggingHook(Hook):
+    """Console lines in the spirit of the reference's prints
+    (recognition_flower/single/flower_train.py:190-193,
+    recognition_flower/distributed/train_dataset.py:190-191)."""
+
+    def __init__(self, every_n_steps: int = 1, worker_index: Optional[int] = None, printer: Callable = print):
+        self.every, self.worker_index, self.printer = max(1, every_n_steps), worker_index, printer
+
+    def after_step(self, session, r):
+        if r.global_step % self.every:
+            return
+        if self.worker_index is None:
+            self.printer("step %d: learning rate %.6f accuracy %.4f loss %.6f (%.1f images/sec)" % (
+                r.global_step, r.learning_rate, r.accuracy, r.loss, r.batch_size / max(r.step_time, 1e-9)))
+        else:
+            self.printer("Worker %d: training step %d done , loss is %f" % (self.worker_index, r.global_step, r.loss))
+
+
+class ThroughputMeter(Hook):
+    """Images/sec over a sliding window of steps (the reference measures no time at all)."""
+
+    def __init__(self, window: int = 20, world_size: int = 1):
+        self.window, self.world = window, world_size
+        self.times: List[float] = []
+        self.images: List[int] = []
+        self.total_images = 0
+        self.t_begin = None
+
+    def begin(self, session):
+        self.t_begin = time.perf_counter()
+
+    def after_step(self, session, r):
+        self.times.append(r.step_time)
+        self.images.append(r.batch_size * self.world)
+        self.total_images += r.batch_size * self.world
+        if len(self.times) > self.window:
+            self.times.pop(0)
+            self.images.pop(0)
+
+    @property
+    def images_per_sec(self) -> float:
+        t = sum(self.times)
+        return sum(self.images) / t if t > 0 else 0.0
+
+
+class CheckpointSaverHook(Hook):
+    """Save every ``save_steps`` global steps (and at the end) through a :class:`io.saver.Saver`."""
+
+    chief_only = True
+
+    def __init__(self, checkpoint_dir: str, save_steps: int, saver, save_at_end: bool = True):
+        self.dir, self.save_steps, self.saver, self.save_at_end = checkpoint_dir, max(1, save_steps), saver, save_at_end
+        self.last_saved = -1
+
+    def after_step(self, session, r):
+        if r.global_step % self.save_steps == 0 and r.global_step != self.last_saved:
+            session.save_checkpoint(self.saver, self.dir, r.global_step)
+            self.last_saved = r.global_step
+
+    def end(self, session):
+        if self.save_at_end and session.global_step != self.last_saved and session.global_step > 0:
+            session.save_checkpoint(self.saver, self.dir, session.global_step)
+            self.last_saved = session.global_step
+
+
+class SummarySaverHook(Hook):
+    """Scalars ``loss`` / ``accuracy`` / ``learning_rate`` and the ``logits histogram``
+    every ``save_steps`` global steps."""
+
+    chief_only = True
+
+    def __init__(self, save_steps: int, output_dir: str, histogram: bool = True):
+        from ..io.events import EventWriter
+
+        self.save_steps = max(1, save_steps)
+        self.writer = EventWriter(output_dir)
+        self.histogram = histogram
+
+    def after_step(self, session, r):
+        if r.global_step % self.save_steps:
+            return
+        scalars = {"loss": r.loss, "accuracy": r.accuracy, "learning_rate": r.learning_rate}
+        scalars.update({k: float(v) for k, v in r.extra.items() if isinstance(v, (int, float))})
+        hist = {}
+        if self.histogram and r.logits is not None:
+            hist["logits histogram"] = r.logits.detach().float().cpu().numpy()
+        self.writer.add_summary(r.global_step, scalars, hist)
+        self.writer.flush()
+
+    def end(self, session):
+        self.writer.close()
+
+
+class TrainingSession:
+    """Runs training steps of ``model`` through ``engine`` and dispatches hooks.
+
+    ``model(images)`` returns logits or ``(logits, regulariser)``.  The loss is
+    mean sparse softmax cross-entropy, plus ``reg_weight * regulariser`` and an
+    optional L2 activity term on the logits -- the reference's loss
+    (recognition_flower/single/flower_train.py:143-145; the distributed script
+    scales the regulariser by 0.01, recognition_flower/distributed/train_dataset.py:159-160).
+    """
+
+    def __init__(self, model, engine, *, num_classes: int, hooks: Optional[List[Hook]] = None, is_chief: bool = True,
+                 reg_weight: float = 1.0, logits_act_l2: float = 0.0, global_step: int = 0,
+                 keep_logits: bool = False):
+        self.model, self.engine = model, engine
+        self.num_classes = num_classes
+        self.is_chief = is_chief
+        self.hooks = [h for h in (hooks or []) if is_chief or not h.chief_only]
+        self.reg_weight, self.logits_act_l2 = reg_weight, logits_act_l2
+        self.global_step = global_step
+        self.keep_logits = keep_logits or any(isinstance(h, SummarySaverHook) for h in self.hooks)
+        self._stop = False
+        self._begun = False
+
+    # ------------------------------------------------------------------ control
+    def request_stop(self) -> None:
+        self._stop = True
+
+    def should_stop(self) -> bool:
+        return self._stop
+
+    def __enter__(self):
+        self._begin()
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.close()
+        return False
+
+    def _begin(self):
+        if not self._begun:
+            for h in self.hooks:
+                h.begin(self)
+            self._begun = True
+
+    def close(self):
+        for h in self.hooks:
+            h.end(self)
+
+    def save_checkpoint(self, saver, directory, step):
+        drain = getattr(self.engine, "drain", None)
+        if drain is not None:
+            drain()
+        return saver.save(directory, step)
+
+    # ------------------------------------------------------------------ steps
+    def compute_loss(self, images, labels):
+        out = self.model(images)
+        logits, reg = out if isinstance(out, tuple) else (out, None)
+        xent, top1, score, correct = F.softmax_xent(logits, labels, self.num_classes, act_l2=self.logits_act_l2)
+        total = xent if reg is None or not self.reg_weight else xent + self.reg_weight * reg
+        return total, xent, logits, top1, score, correct
+
+    def run_step(self, images, labels) -> StepResult:
+        self._begin()
+        t0 = time.perf_counter()
+        self.model.train()
+        self.engine.begin_step()
+        lr = self.engine.optimizer.current_lr()
+        total, xent, logits, top1, score, correct = self.compute_loss(images, labels)
+        total.backward()
+        self.engine.finish_step()
+        self.global_step += 1
+        # .item() synchronises with the device, so step_time covers the whole step
+        loss_v = float(total.detach().float().item())
+        acc = float(correct.float().mean().item())
+        dt = time.perf_counter() - t0
+        r = StepResult(self.global_step, loss_v, acc, lr, int(labels.shape[0]), dt,
+                       logits.detach()[:, :self.num_classes] if self.keep_logits else None,
+                       {"xent": float(xent.detach().float().item())})
+        for h in self.hooks:
+            h.after_step(self, r)
+        return r
+
+    @torch.no_grad()
+    def evaluate(self, images, labels) -> Dict[str, float]:
+        """Inference-mode forward (batch-norm running statistics, no dropout)."""
+        was = self.model.training
+        self.model.eval()
+        try:
+            total, xent, logits, top1, score, correct = self.compute_loss(images, labels)
+        finally:
+            self.model.train(was)
+        return {"loss": float(total.float().item()), "accuracy": float(correct.float().mean().item())}

@@ -1,0 +1,90 @@
+"""Cluster specification: ``TF_CONFIG`` (Kubeflow TFJob style) and torchrun environments.
+
+The reference derives its role from the ``TF_CONFIG`` environment variable::
+
+    {"cluster": {"ps": ["host:port", ...], "worker": ["host:port", ...]},
+     "task": {"type": "ps" | "worker", "index": N}}
+
+(recognition_flower/distributed/train_dataset.py:123-139, distributed/run.sh:3).
+A missing variable yields an empty spec (task type ``None``), which this
+framework treats as single-process training.  For the collective GPU modes the
+same spec is mapped onto a ``torch.distributed`` rendezvous: the workers form
+the process group (rank = worker index), the first worker address is the
+rendezvous endpoint; plain ``torchrun`` variables (RANK / WORLD_SIZE /
+LOCAL_RANK / MASTER_ADDR / MASTER_PORT) are honoured when ``TF_CONFIG`` is
+absent.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+
+@dataclass
+class ClusterSpec:
+    jobs: Dict[str, List[str]] = field(default_factory=dict)
+    task_type: Optional[str] = None
+    task_index: int = 0
+
+    @property
+    def ps_hosts(self) -> List[str]:
+        return self.jobs.get("ps", [])
+
+    @property
+    def worker_hosts(self) -> List[str]:
+        return self.jobs.get("worker", [])
+
+    @property
+    def num_workers(self) -> int:
+        return max(1, len(self.worker_hosts))
+
+    @property
+    def is_chief(self) -> bool:
+        """Worker 0 is the chief.  (The reference computes ``index == 0`` for
+        every job type, so ps 0 also believes it is chief,
+        recognition_flower/distributed/train_dataset.py:138; only workers are
+        chiefs here.)"""
+        return self.task_type in (None, "worker", "chief") and self.task_index == 0
+
+    def address(self, job: str, index: int) -> Tuple[str, int]:
+        host, _, port = self.jobs[job][index].rpartition(":")
+        return host or "127.0.0.1", int(port)
+
+    def my_address(self) -> Tuple[str, int]:
+        return self.address(self.task_type, self.task_index)
+
+
+def parse_tf_config(value: Optional[str] = None) -> ClusterSpec:
+    raw = os.environ.get("TF_CONFIG") if value is None else value
+    cfg = json.loads(raw or "{}")
+    cluster = cfg.get("cluster", {}) or {}
+    task = cfg.get("task", {}) or {}
+    jobs = {str(k): [str(h) for h in v] for k, v in cluster.items()}
+    ttype = task.get("type")
+    idx = int(task.get("index", 0) or 0)
+    if ttype is not None:
+        if ttype not in jobs:
+            raise ValueError("TF_CONFIG task type %r is not a job of the cluster %s" % (ttype, sorted(jobs)))
+        if not 0 <= idx < len(jobs[ttype]):
+            raise ValueError("TF_CONFIG task index %d out of range for job %r" % (idx, ttype))
+    return ClusterSpec(jobs, ttype, idx)
+
+
+def torchrun_env() -> Optional[Tuple[int, int, int]]:
+    """(rank, world_size, local_rank) when launched by torchrun, else None."""
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        return int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    return None
+
+
+def rendezvous_from_cluster(spec: ClusterSpec) -> Dict[str, str]:
+    """Environment for ``torch.distributed.init_process_group(init_method='env://')``
+    built from the worker list of a TF_CONFIG cluster."""
+    if not spec.worker_hosts:
+        raise ValueError("cluster has no workers")
+    host, port = spec.address("worker", 0)
+    return {"MASTER_ADDR": "127.0.0.1" if host in ("localhost", "") else host,
+            "MASTER_PORT": str(port + 1000),
+            "RANK": str(spec.task_index), "WORLD_SIZE": str(len(spec.worker_hosts))}

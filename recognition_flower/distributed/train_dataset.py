@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""Distributed flower classifier training driven by ``TF_CONFIG``.
+
+Entry point with the flags and roles of the reference's
+``recognition_flower/distributed/train_dataset.py`` (flags: lines 10-31 there;
+role dispatch and training loop: 122-192):
+
+    TF_CONFIG='{"cluster": {"ps": [...], "worker": [...]}, "task": {"type": "ps"|"worker", "index": N}}' \
+        python train_dataset.py [--tfrecords_path=./train_v1.tfrecord] [--checkpoint_dir=./output/checkpoint_dir/]
+                                [--summaries_dir=./output/events/] [--train_steps=10] [--batch_size=32]
+                                [--learning_rate=0.001] [--n_epochs=1000] [--model_version=1]
+
+``--mode`` selects how the cluster is realised:
+
+``async_ps`` (default)  the reference's semantics -- ps tasks own the trainable variables and the
+    Adam slots, workers pull / compute / push asynchronously over TCP, ``--train_steps`` is a budget of
+    *global* steps shared by all workers, checkpoints and summaries every 2 global steps.
+    ``--staleness=s`` bounds how far a worker may run ahead (``-1`` = unbounded, as in the reference).
+``sync_dp`` / ``sharded_ps`` / ``async_ssp``  collective modes over ``torch.distributed`` (RCCL on GPUs,
+    gloo on CPUs); only worker tasks take part, ps tasks exit immediately ("every GPU is the ps for
+    1/N of the parameters").  Also usable under ``torchrun`` without ``TF_CONFIG``.
+
+Differences from the reference, on purpose: variables are initialised once (by the chief), file-writing
+hooks run on the chief only, a ps does not wipe the checkpoint directory unless ``--wipe_checkpoint_dir``
+is given, ``--resume`` restores the latest checkpoint, input is RGB in [-1, 1] sharded per worker with
+example-level shuffling, and head dropout defaults to rate 0.2 (the reference's ``keep_prob=0.8`` passed
+as a *rate* drops 80 %; ``--head_dropout_rate=0.8`` reproduces that).
+"""
+import json
+import os
+import shutil
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+
+import torch  # noqa: E402
+
+from distributed_tensorflow_amd.utils import flags  # noqa: E402
+
+flags.DEFINE_integer("model_version", 1, "Version number of the flags.")
+flags.DEFINE_integer("n_epochs", 1000, "Needs to provide the number of epochs as in training.")
+flags.DEFINE_string("tfrecords_path", "./train_v1.tfrecord",
+                    "Needs to provide the tf records file for training.(train_v2~1.15G ,train_v1~38M)")
+flags.DEFINE_string("checkpoint_dir", "./output/checkpoint_dir/",
+                    "Needs to provide the model path (checkpoint,meta) in training.")
+flags.DEFINE_string("summaries_dir", "./output/events/", "Needs to provide the summary output dir in training.")
+flags.DEFINE_integer("train_steps", 10, "Number of training steps to perform")
+flags.DEFINE_integer("batch_size", 32, "Training batch size ")
+flags.DEFINE_float("learning_rate", 0.001, "Learning rate")
+# additions
+flags.DEFINE_string("mode", "async_ps", "async_ps | sync_dp | sharded_ps | async_ssp")
+flags.DEFINE_string("model", "auto", "inception_v3_head | flower_cnn | resnet50 | auto")
+flags.DEFINE_integer("image_size", 299, "Network input size.")
+flags.DEFINE_integer("staleness", -1, "Staleness bound (async_ps: -1 = unbounded; async_ssp: delay in steps).")
+flags.DEFINE_float("bucket_mb", 32.0, "Gradient bucket size for the collective modes.")
+flags.DEFINE_float("head_dropout_rate", 0.2, "Drop probability of the head dropout.")
+flags.DEFINE_integer("save_steps", 2, "Checkpoint / summary period in global steps (the reference uses 2).")
+flags.DEFINE_boolean("resume", False, "Restore the latest checkpoint from checkpoint_dir before training.")
+flags.DEFINE_boolean("wipe_checkpoint_dir", False, "ps task 0 deletes checkpoint_dir at start (reference behaviour).")
+flags.DEFINE_boolean("synthetic", False, "Use synthetic input instead of the TFRecord file.")
+flags.DEFINE_boolean("legacy_bgr_input", False, "Feed BGR [0,255] pixels like the reference's reader.")
+flags.DEFINE_string("device", "auto", "cuda | cpu | auto")
+flags.DEFINE_string("fault_inject", "", "Testing hook: 'exit_at_step:N' makes this worker die abruptly at global step N.")
+flags.DEFINE_boolean("shutdown_ps", True, "The chief stops the ps tasks when it finishes (the reference's ps never exits).")
+flags.DEFINE_float("worker_timeout", 30.0, "Seconds of silence after which a worker no longer counts for the staleness bound.")
+
+FLAGS = flags.FLAGS
+
+params = {
+    "learning_rate": FLAGS.learning_rate,
+    "train_steps": FLAGS.train_steps,
+    "batch_size": FLAGS.batch_size,
+    "num_epochs": FLAGS.n_epochs,
+    "threads": 4,
+}
+
+
+def _device():
+    d = FLAGS.device
+    if d == "auto":
+        d = "cuda" if torch.cuda.is_available() else "cpu"
+    return torch.device(d)
+
+
+def _model_name(device):
+    return FLAGS.model if FLAGS.model != "auto" else ("inception_v3_head" if device.type == "cuda" else "flower_cnn")
+
+
+def _num_classes():
+    meta = FLAGS.tfrecords_path + ".labels.json"
+    if os.path.exists(meta):
+        with open(meta) as f:
+            return len(json.load(f)["classes"])
+    return 5  # the reference hard-codes n_outputs=5
+
+
+def train_input_fn(tfrecords_path, params, device, rank, world):
+    from distributed_tensorflow_amd.data.records import RecordInput, SyntheticInput
+
+    if FLAGS.synthetic:
+        return SyntheticInput(params["batch_size"], FLAGS.image_size, device, seed=rank)
+    return RecordInput(tfrecords_path, params["batch_size"], device, image_size=FLAGS.image_size,
+                       num_epochs=params["num_epochs"], rank=rank, world=world, threads=params["threads"],
+                       prefetch=4, shuffle=True, seed=1234, legacy_bgr_unnormalised=FLAGS.legacy_bgr_input)
+
+
+def run_ps(spec):
+    from distributed_tensorflow_amd.parallel.ps import ParameterServer
+
+    if FLAGS.mode != "async_ps":
+        print("ps task %d: mode %s keeps parameters on the workers; nothing to serve" % (spec.task_index, FLAGS.mode))
+        return 0
+    if FLAGS.wipe_checkpoint_dir and spec.task_index == 0 and os.path.exists(FLAGS.checkpoint_dir):
+        shutil.rmtree(FLAGS.checkpoint_dir)
+    host, port = spec.my_address()
+    server = ParameterServer("0.0.0.0" if host not in ("localhost", "127.0.0.1") else "127.0.0.1", port,
+                             ps_index=spec.task_index, staleness=FLAGS.staleness, worker_timeout=FLAGS.worker_timeout)
+    print("ps %d serving on port %d" % (spec.task_index, port), flush=True)
+    server.serve_forever()  # the counterpart of server.join()
+    print("ps %d stopped at global step %d" % (spec.task_index, server.global_step))
+    return 0
+
+
+def run_worker(spec):
+    from distributed_tensorflow_amd.io.saver import Saver
+    from distributed_tensorflow_amd.models import build_model
+    from distributed_tensorflow_amd.parallel.ps import PSStopped
+    from distributed_tensorflow_amd.train.session import (CheckpointSaverHook, LoggingHook, StopAtStepHook,
+                                                          SummarySaverHook, ThroughputMeter, TrainingSession)
+    from distributed_tensorflow_amd.utils.cluster import rendezvous_from_cluster, torchrun_env
+
+    device = _device()
+    task_index = spec.task_index
+    world = spec.num_workers
+    tr = torchrun_env()
+    if spec.task_type is None and tr is not None:
+        task_index, world = tr[0], tr[1]
+        if device.type == "cuda":
+            torch.cuda.set_device(tr[2])
+            device = torch.device("cuda", tr[2])
+    is_chief = task_index == 0
+    torch.manual_seed(1234)  # identical initial values on every worker
+    model_name = _model_name(device)
+    n_classes = _num_classes()
+    kw = {"head_dropout_rate": FLAGS.head_dropout_rate} if model_name == "inception_v3_head" else (
+        {"dropout_rate": FLAGS.head_dropout_rate} if model_name == "flower_cnn" else {})
+    model = build_model(model_name, num_classes=n_classes, device=device, **kw)
+
+    if FLAGS.mode == "async_ps" and spec.ps_hosts:
+        from distributed_tensorflow_amd.parallel.ps import PSWorkerEngine
+
+        ps_addr = [spec.address("ps", i) for i in range(len(spec.ps_hosts))]
+        ps_addr = [("127.0.0.1" if h == "localhost" else h, p) for h, p in ps_addr]
+        engine = PSWorkerEngine(model, ps_addr, task_index, is_chief, optimizer="adam",
+                                lr=params["learning_rate"])
+    else:
+        import torch.distributed as dist
+        from distributed_tensorflow_amd.parallel.engine import DataParallelEngine
+
+        if world > 1 and not dist.is_initialized():
+            if tr is None:
+                os.environ.update(rendezvous_from_cluster(spec))
+            dist.init_process_group("nccl" if device.type == "cuda" else "gloo", rank=task_index, world_size=world)
+        mode = "sync_dp" if FLAGS.mode == "async_ps" else FLAGS.mode
+        engine = DataParallelEngine(model, mode=mode, optimizer="adam", lr=params["learning_rate"],
+                                    bucket_mb=FLAGS.bucket_mb, staleness=max(FLAGS.staleness, 0))
+    saver = Saver(model, engine)
+    start_step = 0
+    if FLAGS.resume and is_chief:
+        restored = saver.restore_latest(FLAGS.checkpoint_dir)
+        if restored is not None:
+            start_step = restored
+            print("resumed from global step", restored)
+
+    hooks = [StopAtStepHook(params["train_steps"]),
+             CheckpointSaverHook(FLAGS.checkpoint_dir, FLAGS.save_steps, saver),
+             SummarySaverHook(FLAGS.save_steps, os.path.join(FLAGS.summaries_dir + str(FLAGS.model_version), "train")),
+             ThroughputMeter(world_size=world),
+             LoggingHook(2, worker_index=task_index)]
+    head_l2 = getattr(getattr(model, "head", None), "act_l2", 0.0)
+    # the reference scales the activity regulariser by 0.01 in this script (train_dataset.py:159-160)
+    sess = TrainingSession(model, engine, num_classes=n_classes, hooks=hooks, is_chief=is_chief, reg_weight=0.01,
+                           logits_act_l2=0.01 * head_l2, global_step=start_step)
+    data = train_input_fn(FLAGS.tfrecords_path, params, device, task_index, world)
+    fault_step = int(FLAGS.fault_inject.split(":")[1]) if FLAGS.fault_inject.startswith("exit_at_step:") else None
+    t0 = time.time()
+    with sess:
+        step = getattr(engine, "global_step", start_step)
+        while not sess.should_stop() and step < params["train_steps"]:
+            try:
+                x, y = next(data)
+            except StopIteration:  # input exhausted after n_epochs, like OutOfRangeError
+                break
+            try:
+                r = sess.run_step(x, y)
+            except PSStopped:
+                print("Worker %d: parameter server finished the step budget" % task_index)
+                break
+            gs = getattr(engine, "global_step", None)
+            if gs is not None and FLAGS.mode == "async_ps":
+                sess.global_step = step = int(gs)  # the step budget is global, shared by all workers
+            else:
+                step = r.global_step
+            if fault_step is not None and step >= fault_step:
+                print("Worker %d: injected fault at step %d" % (task_index, step), flush=True)
+                os._exit(17)
+    print("finished training (worker %d, %.1fs, global step %d)" % (task_index, time.time() - t0, step))
+    if hasattr(engine, "close"):
+        engine.close(shutdown_ps=FLAGS.shutdown_ps and is_chief)
+    if hasattr(data, "close"):
+        data.close()
+    return 0
+
+
+def main(unused_argv):
+    from distributed_tensorflow_amd.utils.cluster import parse_tf_config
+
+    print(os.environ.get("TF_CONFIG"))
+    spec = parse_tf_config()
+    if spec.task_type == "ps":
+        return run_ps(spec)
+    return run_worker(spec)
+
+
+if __name__ == "__main__":
+    flags.run(main)

@@ -1,0 +1,147 @@
+#!/usr/bin/env python
+"""Single-process flower classifier training + servable export.
+
+Entry point with the flags of the reference's
+``recognition_flower/single/flower_train.py`` (flags: lines 10-31 there; loop:
+170-193; export: 195-251):
+
+    python flower_train.py [--output_dir=../output/models] [--model_version=1] [--image_size=299]
+                           [--n_epochs=10] [--dataset_path=../flower_photos_labeled]
+                           [--model_path=] [--summaries_dir=../output/events/]
+
+Behaviour kept: class-per-directory dataset listing with an 80/20 split, batches
+of 32 augmented crops in [-1, 1], Inception-v3 trunk (frozen) + 2048-1024-5 head
+trained with Adam under ``exponential_decay(0.001, 200, 0.95)``, loss = mean
+softmax cross-entropy + L2 activity terms, per-step console log, TensorBoard
+scalars (learning_rate / loss / accuracy) and ``logits histogram``, optional
+restore from ``--model_path``, export of a servable with the ``serving_default``
+and ``predict_images`` signatures under ``<output_dir>/<model_version>``.
+
+Deliberate differences: accuracy is taken from the training forward pass (the
+reference runs a second full forward per step for it), summaries are indexed by
+global step (the reference uses the epoch index), the held-out 20 % is actually
+evaluated at the end, and on a GPU the JPEG decode / augmentation / resize run
+on the device.  ``--model=flower_cnn`` trains the small end-to-end CNN instead
+(the default on a machine without a GPU).
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from distributed_tensorflow_amd.utils import flags  # noqa: E402
+
+flags.DEFINE_string("output_dir", "../output/models", "Directory where to export the model.")
+flags.DEFINE_integer("model_version", 1, "Version number of the model.")
+flags.DEFINE_integer("image_size", 299, "Needs to provide same value as in training.")
+flags.DEFINE_integer("n_epochs", 10, "Needs to provide the number of epochs as in training.")
+flags.DEFINE_string("dataset_path", "../flower_photos_labeled", "Needs to provide the dataset path as in training.")
+flags.DEFINE_string("model_path", "", "Checkpoint prefix to restore before training (optional).")
+flags.DEFINE_string("summaries_dir", "../output/events/", "Needs to provide the summary output dir in training.")
+# additions
+flags.DEFINE_string("model", "auto", "inception_v3_head | flower_cnn | resnet50 | auto (inception on GPU, flower_cnn on CPU)")
+flags.DEFINE_integer("batch_size", 32, "Training batch size (the reference hard-codes 32).")
+flags.DEFINE_float("learning_rate", 0.001, "Initial learning rate of the exponential decay schedule.")
+flags.DEFINE_float("head_dropout_rate", 0.5, "Drop probability of the head dropout (the reference feeds 0.5).")
+flags.DEFINE_string("device", "auto", "cuda | cpu | auto")
+flags.DEFINE_integer("max_steps", 0, "Stop after this many steps (0 = n_epochs * iterations per epoch).")
+flags.DEFINE_integer("seed", 42, "Random seed.")
+flags.DEFINE_string("checkpoint_dir", "", "Also write a training checkpoint here at the end (optional).")
+flags.DEFINE_boolean("export", True, "Export the servable at the end.")
+
+FLAGS = flags.FLAGS
+
+
+def main(argv):
+    from distributed_tensorflow_amd.data import flowers
+    from distributed_tensorflow_amd.io.export import export_servable
+    from distributed_tensorflow_amd.io.saver import Saver
+    from distributed_tensorflow_amd.models import build_model
+    from distributed_tensorflow_amd.optim import exponential_decay
+    from distributed_tensorflow_amd.parallel.engine import DataParallelEngine
+    from distributed_tensorflow_amd.train.session import (LoggingHook, SummarySaverHook, ThroughputMeter,
+                                                          TrainingSession)
+    import flower_input_data
+
+    device = FLAGS.device
+    if device == "auto":
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    device = torch.device(device)
+    model_name = FLAGS.model
+    if model_name == "auto":
+        model_name = "inception_v3_head" if device.type == "cuda" else "flower_cnn"
+    torch.manual_seed(FLAGS.seed)
+    np_rng = np.random.default_rng(FLAGS.seed)
+
+    flowers_root_path = FLAGS.dataset_path
+    flower_classes = flowers.list_classes(flowers_root_path)
+    items = flowers.get_image_path_and_class(flowers_root_path, flower_classes)
+    train, test = flowers.train_test_split(items, test_ratio=0.2, seed=FLAGS.seed)
+    print("classes:", flower_classes, "| train", len(train), "test", len(test))
+
+    batch_size = min(FLAGS.batch_size, len(train))
+    n_iterations_per_epoch = max(1, len(train) // batch_size)
+    kw = {"head_dropout_rate": FLAGS.head_dropout_rate} if model_name == "inception_v3_head" else (
+        {"dropout_rate": FLAGS.head_dropout_rate} if model_name == "flower_cnn" else {})
+    model = build_model(model_name, num_classes=len(flower_classes), device=device, **kw)
+    engine = DataParallelEngine(model, mode="sync_dp", optimizer="adam",
+                                lr=exponential_decay(FLAGS.learning_rate, decay_steps=200, decay_rate=0.95))
+    saver = Saver(model, engine)
+    global_step = 0
+    if FLAGS.model_path:
+        global_step = saver.restore(FLAGS.model_path)
+        print("restored", FLAGS.model_path, "at global step", global_step)
+
+    meter = ThroughputMeter()
+    hooks = [SummarySaverHook(1, os.path.join(FLAGS.summaries_dir + str(FLAGS.model_version), "train")), meter,
+             LoggingHook(1)]
+    head_l2 = getattr(getattr(model, "head", None), "act_l2", 0.0)
+    sess = TrainingSession(model, engine, num_classes=len(flower_classes), hooks=hooks, global_step=global_step,
+                           logits_act_l2=head_l2)
+
+    def next_batch(pool, bs):
+        if device.type == "cuda":
+            return flower_input_data.prepare_batch_on_device(pool, bs, device, FLAGS.image_size, np_rng=np_rng)
+        X, y = flowers.prepare_batch(pool, bs, FLAGS.image_size, np_rng)
+        Xp = np.zeros(X.shape[:3] + (8,), dtype=np.float32)
+        Xp[..., :3] = X
+        return torch.from_numpy(Xp), torch.from_numpy(y)
+
+    t0 = time.time()
+    done = False
+    with sess:
+        for epoch in range(FLAGS.n_epochs):
+            print("Epoch", epoch, end="\n")
+            for _ in range(n_iterations_per_epoch):
+                X, y = next_batch(train, batch_size)
+                sess.run_step(X, y)
+                if FLAGS.max_steps and sess.global_step - global_step >= FLAGS.max_steps:
+                    done = True
+                    break
+            if done:
+                break
+        if test:
+            bs = min(len(test), batch_size)
+            X, y = next_batch(test, bs)
+            ev = sess.evaluate(X, y)
+            print("held-out batch: accuracy %.4f loss %.4f" % (ev["accuracy"], ev["loss"]))
+        if FLAGS.checkpoint_dir:
+            print("checkpoint:", sess.save_checkpoint(saver, FLAGS.checkpoint_dir, sess.global_step))
+    print("trained %d steps in %.1fs (%.1f images/sec)" % (sess.global_step - global_step, time.time() - t0,
+                                                           meter.images_per_sec))
+
+    if FLAGS.export:
+        path = export_servable(model, flower_classes, FLAGS.output_dir, FLAGS.model_version, model_name=model_name,
+                               image_size=FLAGS.image_size, model_kwargs=kw, engine=engine,
+                               global_step=sess.global_step)
+        print("Exported servable to", path)
+    print("Done exporting!")
+    return 0
+
+
+if __name__ == "__main__":
+    flags.run(main)
