@@ -63,6 +63,33 @@ def decode_reference(data: bytes) -> np.ndarray:
     return decode_pil(data)
 
 
+def reconstruct_reference(info, coefs: np.ndarray) -> np.ndarray:
+    """numpy version of the GPU half (dequantise, float IDCT, replicate chroma, YCbCr->RGB);
+    the oracle for ``csrc/hip/jpeg.hip`` and a check of the entropy decoder against libjpeg."""
+    x = np.arange(8)
+    cosm = np.cos((2 * x[:, None] + 1) * x[None, :] * np.pi / 16) * np.where(x[None, :] == 0, np.sqrt(0.125), 0.5)
+    planes = []
+    for c in range(info.ncomp):
+        bw, bh = info.blocks_w[c], info.blocks_h[c]
+        blk = coefs[info.coef_offset[c]: info.coef_offset[c] + bw * bh * 64].astype(np.float32).reshape(bh, bw, 8, 8)
+        blk = blk * np.asarray(info.qt[c], dtype=np.float32).reshape(8, 8)
+        pix = np.einsum("yv,hwvu,xu->hwyx", cosm.astype(np.float32), blk, cosm.astype(np.float32))
+        pix = np.clip(np.rint(pix) + 128, 0, 255)
+        planes.append(pix.transpose(0, 2, 1, 3).reshape(bh * 8, bw * 8))
+    H, W = info.height, info.width
+    ys, xs = np.arange(H), np.arange(W)
+    comps = []
+    for c in range(info.ncomp):
+        cy = ys * info.vs[c] // info.vmax
+        cx = xs * info.hs[c] // info.hmax
+        comps.append(planes[c][cy][:, cx])
+    if info.ncomp == 1:
+        return np.repeat(comps[0][:, :, None], 3, axis=2).astype(np.uint8)
+    Y, cb, cr = comps[0], comps[1] - 128.0, comps[2] - 128.0
+    rgb = np.stack([Y + 1.402 * cr, Y - 0.344136 * cb - 0.714136 * cr, Y + 1.772 * cb], axis=2)
+    return np.clip(np.rint(rgb), 0, 255).astype(np.uint8)
+
+
 _pool: Optional[ThreadPoolExecutor] = None
 
 

@@ -158,6 +158,12 @@ class Saver:
                     out[spec.name + "/" + SLOT_SUFFIX.get(slot, slot)] = spec.to_tf(sv.float()).cpu().numpy()
         return out
 
+    def gather_only(self) -> None:
+        """Non-chief ranks of a sharded run: participate in the collectives ``save`` performs."""
+        if self.engine is not None:
+            self.engine.full_master()
+            self.engine.full_slots()
+
     # ------------------------------------------------------------------ save
     def save(self, checkpoint_dir: str, global_step: int, write_state: bool = True,
              extra: Optional[Dict[str, np.ndarray]] = None) -> str:

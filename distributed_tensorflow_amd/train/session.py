@@ -104,6 +104,7 @@ class CheckpointSaverHook(Hook):
     """Save every ``save_steps`` global steps (and at the end) through a :class:`io.saver.Saver`."""
 
     chief_only = True
+    collective = True  # with sharded ownership every rank must take part in gathering the shards
 
     def __init__(self, checkpoint_dir: str, save_steps: int, saver, save_at_end: bool = True):
         self.dir, self.save_steps, self.saver, self.save_at_end = checkpoint_dir, max(1, save_steps), saver, save_at_end
@@ -164,7 +165,9 @@ class TrainingSession:
         self.model, self.engine = model, engine
         self.num_classes = num_classes
         self.is_chief = is_chief
-        self.hooks = [h for h in (hooks or []) if is_chief or not h.chief_only]
+        needs_all_ranks = getattr(engine, "mode", "") == "sharded_ps" and getattr(engine, "world", 1) > 1
+        self.hooks = [h for h in (hooks or [])
+                      if is_chief or not h.chief_only or (needs_all_ranks and getattr(h, "collective", False))]
         self.reg_weight, self.logits_act_l2 = reg_weight, logits_act_l2
         self.global_step = global_step
         self.keep_logits = keep_logits or any(isinstance(h, SummarySaverHook) for h in self.hooks)
@@ -201,6 +204,9 @@ class TrainingSession:
         drain = getattr(self.engine, "drain", None)
         if drain is not None:
             drain()
+        if not self.is_chief:
+            saver.gather_only()  # join the shard all-gathers; only the chief writes files
+            return None
         return saver.save(directory, step)
 
     # ------------------------------------------------------------------ steps

@@ -167,7 +167,9 @@ def run_worker(spec):
                                     bucket_mb=FLAGS.bucket_mb, staleness=max(FLAGS.staleness, 0))
     saver = Saver(model, engine)
     start_step = 0
-    if FLAGS.resume and is_chief:
+    # async_ps: the chief restores and uploads to the ps tasks; collective modes: every rank loads the file
+    collective = not (FLAGS.mode == "async_ps" and spec.ps_hosts)
+    if FLAGS.resume and (is_chief or collective):
         restored = saver.restore_latest(FLAGS.checkpoint_dir)
         if restored is not None:
             start_step = restored

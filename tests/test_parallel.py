@@ -1,0 +1,183 @@
+"""Collective data-parallel engine on CPU tensors with gloo (world size 2).
+
+The same engine code runs over RCCL on GPUs; these tests pin down the
+arithmetic: gradient averaging, equivalence of the all-reduce and the
+reduce-scatter / all-gather (sharded parameter ownership) formulations, and
+the staleness semantics of the delayed-apply mode.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from distributed_tensorflow_amd.models import build_model
+from distributed_tensorflow_amd.ops import functional as F
+from distributed_tensorflow_amd.parallel.engine import DataParallelEngine
+from distributed_tensorflow_amd.parallel.flat import FlatParams
+
+WIDTHS = (8, 8, 16, 16, 16)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(rank, step, size=32, n=4):
+    g = torch.Generator().manual_seed(1000 * rank + step)
+    x = torch.zeros(n, size, size, 8)
+    x[..., :3] = torch.randn(n, size, size, 3, generator=g)
+    return x, torch.randint(0, 5, (n,), generator=g)
+
+
+def _model():
+    torch.manual_seed(7)
+    return build_model("flower_cnn", widths=WIDTHS, dropout_rate=0.0)
+
+
+def _loss(model, x, y):
+    logits, reg = model(x)
+    loss, _, _, _ = F.softmax_xent(logits, y, 5)
+    return loss + reg
+
+
+def _worker(rank, world, port, mode, opt, steps, staleness, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _model()
+        if rank == 1:  # replicas must be synchronised from rank 0 by the engine
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(1.0)
+        okw = {"momentum": 0.9, "weight_decay": 1e-3} if opt == "momentum" else {}
+        eng = DataParallelEngine(model, mode=mode, optimizer=opt, lr=0.05 if opt == "momentum" else 1e-2,
+                                 opt_kwargs=okw, bucket_mb=0.02, staleness=staleness)
+        for t in range(steps):
+            eng.begin_step()
+            _loss(model, *_batch(rank, t)).backward()
+            eng.finish_step()
+        eng.drain()
+        eng.full_master()  # (sharded mode: gathers the owners' fp32 shards back into FlatGroup.master)
+        # compare parameter by parameter: bucket padding differs between modes, values must not
+        flat = torch.cat([g.master[s.offset:s.offset + s.numel].clone() for g in eng.flat.groups for s in g.segments])
+        compute = torch.cat([p.detach().float().reshape(-1).clone() for p in eng.flat.params])
+        torch.save({"flat": flat, "compute": compute}, os.path.join(out_dir, "%s_%s_r%d.pt" % (mode, opt, rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(mode, opt, steps, staleness, out_dir):
+    mp.spawn(_worker, args=(2, _free_port(), mode, opt, steps, staleness, out_dir), nprocs=2, join=True)
+    return [torch.load(os.path.join(out_dir, "%s_%s_r%d.pt" % (mode, opt, r))) for r in range(2)]
+
+
+def _reference(opt, steps, delay=0):
+    """Single process: per-replica gradients computed separately (each replica has its own
+    batch-norm statistics), averaged, applied -- optionally ``delay`` steps late."""
+    models = [_model(), _model()]
+    okw = {"momentum": 0.9, "weight_decay": 1e-3} if opt == "momentum" else {}
+    engs = [DataParallelEngine(m, mode="sync_dp", optimizer=opt, lr=0.05 if opt == "momentum" else 1e-2,
+                               opt_kwargs=okw, bucket_mb=0.02) for m in models]
+    pending = []
+    for t in range(steps):
+        grads = []
+        for r, (m, e) in enumerate(zip(models, engs)):
+            e.begin_step()
+            _loss(m, *_batch(r, t)).backward()
+            e.flat.collect_autograd_grads()
+            grads.append([g.grad.clone() for g in e.flat.groups])
+        pending.append([(a + b) for a, b in zip(*grads)])
+        if len(pending) > delay:
+            avg = pending.pop(0)
+            for e in engs:
+                for g, s in zip(e.flat.groups, avg):
+                    g.grad.copy_(s)
+                e.optimizer.step(grad_scale=0.5)
+    for avg in pending:
+        for e in engs:
+            for g, s in zip(e.flat.groups, avg):
+                g.grad.copy_(s)
+            e.optimizer.step(grad_scale=0.5)
+    return torch.cat([g.master[s.offset:s.offset + s.numel] for g in engs[0].flat.groups for s in g.segments])
+
+
+@pytest.mark.parametrize("opt", ["momentum", "adam"])
+def test_sync_dp_matches_manual_gradient_averaging(tmp_path, opt):
+    res = _spawn("sync_dp", opt, 3, 0, str(tmp_path))
+    torch.testing.assert_close(res[0]["flat"], res[1]["flat"], rtol=0, atol=0)  # replicas identical
+    torch.testing.assert_close(res[0]["flat"], _reference(opt, 3), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("opt", ["momentum", "adam"])
+def test_sharded_ps_is_bitwise_equal_to_allreduce_dp(tmp_path, opt):
+    a = _spawn("sync_dp", opt, 3, 0, str(tmp_path))
+    b = _spawn("sharded_ps", opt, 3, 0, str(tmp_path))
+    # reduce-scatter + owner update + all-gather == all-reduce + replicated update, bit for bit in fp32
+    torch.testing.assert_close(b[0]["flat"], a[0]["flat"], rtol=0, atol=0)
+    torch.testing.assert_close(b[0]["compute"], b[1]["compute"], rtol=0, atol=0)
+    torch.testing.assert_close(b[0]["compute"], a[0]["compute"], rtol=0, atol=0)
+
+
+def test_async_ssp_applies_gradients_exactly_s_steps_late(tmp_path):
+    s0 = _spawn("async_ssp", "momentum", 4, 0, str(tmp_path))
+    sync = _spawn("sync_dp", "momentum", 4, 0, str(tmp_path))
+    torch.testing.assert_close(s0[0]["flat"], sync[0]["flat"], rtol=0, atol=0)  # s = 0 degenerates to sync
+    s2 = _spawn("async_ssp", "momentum", 4, 2, str(tmp_path))
+    torch.testing.assert_close(s2[0]["flat"], s2[1]["flat"], rtol=0, atol=0)
+    torch.testing.assert_close(s2[0]["flat"], _reference("momentum", 4, delay=2), rtol=1e-5, atol=1e-6)
+    assert not torch.equal(s2[0]["flat"], sync[0]["flat"])
+
+
+def test_async_ssp_first_s_steps_leave_parameters_untouched():
+    model = _model()
+    eng = DataParallelEngine(model, mode="async_ssp", optimizer="momentum", lr=0.05, staleness=2, bucket_mb=0.02)
+    before = torch.cat([g.master.clone() for g in eng.flat.groups])
+    for t in range(2):
+        eng.begin_step()
+        _loss(model, *_batch(0, t)).backward()
+        eng.finish_step()
+        torch.testing.assert_close(torch.cat([g.master for g in eng.flat.groups]), before, rtol=0, atol=0)
+    eng.begin_step()
+    _loss(model, *_batch(0, 2)).backward()
+    eng.finish_step()  # step 0's gradient lands now
+    assert not torch.equal(torch.cat([g.master for g in eng.flat.groups]), before)
+
+
+def test_flat_params_bucket_layout():
+    model = _model()
+    flat = FlatParams(model, bucket_mb=0.02, shard_multiple=8)
+    for g in flat.groups:
+        assert g.total % (8 * 64) == 0
+        prev_end = 0
+        for b in g.buckets:
+            assert b.start == prev_end and b.numel % (8 * 64) == 0
+            prev_end = b.end
+            for s in b.segments:
+                assert b.start <= s.offset and s.offset + s.numel <= b.end and s.offset % 64 == 0
+        assert prev_end == g.total
+        assert len(g.buckets) > 1
+    # parameters are views into the flat buffers, laid out last-layer-first
+    first = flat.groups[0].segments[0]
+    assert first.name.startswith("head.")
+    p = dict(model.named_parameters())[first.name]
+    assert p.data_ptr() == flat.groups[0].compute[first.offset:].data_ptr()
+    assert p.main_grad.data_ptr() == flat.groups[0].grad[first.offset:].data_ptr()
+
+
+def test_bucket_ready_callbacks_fire_once_per_bucket():
+    model = _model()
+    flat = FlatParams(model, bucket_mb=0.02)
+    fired = []
+    flat.on_bucket_ready = lambda b: fired.append((b.group.name, b.index))
+    flat.begin_step()
+    _loss(model, *_batch(0, 0)).backward()
+    flat.collect_autograd_grads()
+    assert sorted(fired) == sorted((g.name, b.index) for g in flat.groups for b in g.buckets)
+    assert len(set(fired)) == len(fired)
