@@ -202,28 +202,43 @@ __global__ void col_partials_kernel(const bf16* __restrict__ a, const bf16* __re
     long long r0 = (long long)blockIdx.y * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    for (long long r = r0 + ty; r < r1; r += TY) {
-      size_t off = (size_t)r * C + (size_t)cg * 8;
-      bf16x8 v = *(const bf16x8*)(a + off);
-      if (MODE == 0) {
+    // U rows per iteration: all loads of an iteration are issued before any of them is consumed
+    constexpr int U = 4;
+    for (long long r = r0 + ty; r < r1; r += (long long)TY * U) {
+      bf16x8 v[U], yy[U], zz[U];
+      bool ok[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float f = (float)v[j];
-          s1[j] += f;
-          s2[j] += f * f;
+      for (int u = 0; u < U; ++u) {
+        long long rr = r + (long long)u * TY;
+        ok[u] = rr < r1;
+        size_t off = (size_t)(ok[u] ? rr : r) * C + (size_t)cg * 8;
+        v[u] = *(const bf16x8*)(a + off);
+        if (MODE == 1) {
+          yy[u] = *(const bf16x8*)(yv + off);
+          if (relu == 1) zz[u] = *(const bf16x8*)(zout + off);
         }
-      } else {
-        bf16x8 yy = *(const bf16x8*)(yv + off);
-        bf16x8 zz;
-        if (relu == 1) zz = *(const bf16x8*)(zout + off);
+      }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float g = (float)v[j];
-          if (relu == 1 && !((float)zz[j] > 0.f)) g = 0.f;
-          if (relu == 2 && !((float)yy[j] * sc[j] + sh[j] > 0.f)) g = 0.f;
-          float xh = ((float)yy[j] - mu[j]) * is[j];
-          s1[j] += g;
-          s2[j] += g * xh;
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+        if (MODE == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float f = (float)v[u][j];
+            s1[j] += f;
+            s2[j] += f * f;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float g = (float)v[u][j];
+            float yf = (float)yy[u][j];
+            if (relu == 1 && !((float)zz[u][j] > 0.f)) g = 0.f;
+            if (relu == 2 && !(yf * sc[j] + sh[j] > 0.f)) g = 0.f;
+            float xh = (yf - mu[j]) * is[j];
+            s1[j] += g;
+            s2[j] += g * xh;
+          }
         }
       }
     }

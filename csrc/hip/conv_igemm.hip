@@ -32,6 +32,7 @@ struct ConvArgs {
   const bf16* w;
   bf16* y;
   const float* bias;   // [Cout] or null
+  const bf16* addend;  // optional tensor of the output's shape, added in the epilogue (residual gradient)
   float* stats;        // [mtiles*2][2][Cout] partial (sum, sumsq) or null
   const bf16* zero;    // >= 16 bytes of zeros, 16-byte aligned
   const int* taps;     // T entries, (dy << 16) | (dx & 0xffff)
@@ -179,21 +180,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   for (int kt = 0; kt < KT; ++kt) {
     if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
     const char* base = lds_tiles + cur * STAGE;
+    // fragments of k-step ks+1 are fetched from LDS while the MFMAs of k-step ks run
+    bf16x8 af[2][MT], bfr[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[0][mt] = *(const bf16x8*)(base + aoff[mt] + ((khalf ^ aswz[mt]) << 4));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bfr[0][nt] = *(const bf16x8*)(base + boff[nt] + ((khalf ^ bswz[nt]) << 4));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 af[MT], bfr[NT];
-      const int sl = ks * 2 + khalf;
+      const int c = ks & 1, n = c ^ 1;
+      if (ks + 1 < KS) {
+        const int sl = (ks + 1) * 2 + khalf;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        af[mt] = *(const bf16x8*)(base + aoff[mt] + ((sl ^ aswz[mt]) << 4));
+        for (int mt = 0; mt < MT; ++mt)
+          af[n][mt] = *(const bf16x8*)(base + aoff[mt] + ((sl ^ aswz[mt]) << 4));
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        bfr[nt] = *(const bf16x8*)(base + boff[nt] + ((sl ^ bswz[nt]) << 4));
+        for (int nt = 0; nt < NT; ++nt)
+          bfr[n][nt] = *(const bf16x8*)(base + boff[nt] + ((sl ^ bswz[nt]) << 4));
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][mt], bfr[c][nt], acc[mt][nt], 0, 0, 0);
     }
     wait_vmcnt0();
     __syncthreads();
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     int m = m0 + wr * WM + r;
     int co = n0 + wc * WN + c * 8;
     if (m < p.M && co < p.Cout) {
-      uint4 v = *(const uint4*)(ep + r * EP_PITCH + c * 16);
+      bf16x8 v = *(const bf16x8*)(ep + r * EP_PITCH + c * 16);
       size_t opixel;
       if (p.dense_out) {
         opixel = (size_t)m;
@@ -255,7 +264,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         int ox = rem - oy * p.OXn;
         opixel = ((size_t)b * p.OH + (oy * p.osy + p.oy0)) * p.OW + (ox * p.osx + p.ox0);
       }
-      *(uint4*)(p.y + opixel * p.Cout + co) = v;
+      if (p.addend != nullptr) {
+        bf16x8 a = *(const bf16x8*)(p.addend + opixel * p.Cout + co);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)a[j]);
+      }
+      *(bf16x8*)(p.y + opixel * p.Cout + co) = v;
     }
   }
 }

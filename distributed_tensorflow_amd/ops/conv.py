@@ -161,17 +161,19 @@ def _env_tile(name: str):
 
 
 def pick_fwd_tile(M: int, cout: int, K: int) -> Tuple[int, int, int]:
+    """(BM, BN, BK) of the implicit-GEMM kernel.  Chosen from a sweep over the ResNet-50 layer shapes
+    at batch 256 on MI355X (tools/sweep_conv.py): deep reductions (3x3 convs, K >= 576) want BK = 64;
+    short ones (1x1 convs, memory-bound) want BK = 32 and the higher occupancy it allows; the 256-row
+    tile never won."""
     forced = _env_tile("DTFA_CONV_TILE")
     if forced:
         return forced  # type: ignore[return-value]
-    bk = 64 if K % 64 == 0 and K >= 256 else 32
+    bk = 64 if K >= 576 else 32
     bn = 128 if cout > 64 else 64
     bm = 128
     tiles = -(-M // bm) * -(-cout // bn)
     if bn == 64 and tiles < 512:
         bm = 64
-    elif bn == 128 and tiles >= 2048 and cout % 128 == 0:
-        bm = 256
     return bm, bn, bk
 
 
@@ -194,7 +196,7 @@ def pick_wgrad_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
 # launches
 # --------------------------------------------------------------------------
 def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, osx, oy0, ox0, isy, isx, B,
-                  cin_magic, bias=None, relu=False, stats=False):
+                  cin_magic, bias=None, relu=False, stats=False, addend=None):
     M = B * oyn * oxn
     K = T * cin
     bm, bn, bk = pick_fwd_tile(M, cout, K)
@@ -206,6 +208,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     a = hipk.ConvArgs()
     a.x, a.w, a.y = x.data_ptr(), w2d.data_ptr(), y.data_ptr()
     a.bias = hipk.ptr(bias)
+    a.addend = hipk.ptr(addend)
     a.stats = hipk.ptr(part)
     a.zero = hipk.zero_page(x.device).data_ptr()
     a.taps = taps.data_ptr()
@@ -246,8 +249,9 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
     return y, part
 
 
-def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan) -> torch.Tensor:
-    """dy [B,OH,OW,Cout] -> dx [B,IH,IW,Cin]."""
+def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy [B,OH,OW,Cout] -> dx [B,IH,IW,Cin] (+ ``addend``, e.g. the gradient arriving over a
+    residual connection, fused into the epilogue instead of a separate add pass)."""
     hipk.require(dy, torch.bfloat16, "dy")
     hipk.require(w, torch.bfloat16, "w")
     B = dy.shape[0]
@@ -256,6 +260,12 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan) -> torch.Tenso
     if w.numel() != plan.cout * plan.K:
         raise ValueError("weight shape does not match plan")
     L = hipk.lib()
+    if addend is not None:
+        hipk.require(addend, torch.bfloat16, "addend")
+        if tuple(addend.shape) != (B, plan.ih, plan.iw, plan.cin):
+            raise ValueError("addend shape does not match dx")
+        if plan.dgrad_needs_zero:
+            raise ValueError("addend fusion needs every input pixel to be written by a dgrad phase")
     if plan.dgrad_needs_zero:
         dx = torch.zeros((B, plan.ih, plan.iw, plan.cin), dtype=torch.bfloat16, device=dy.device)
     else:
@@ -265,7 +275,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan) -> torch.Tenso
         hipk.check(L.dtfa_weight_permute(w.data_ptr(), wd.data_ptr(), ph.src_tap.data_ptr(), plan.cout, plan.T,
                                          plan.cin, ph.T, hipk.stream()), "weight_permute")
         _launch_igemm(dy, wd, dx, ph.taps, ph.T, plan.oh, plan.ow, plan.cout, plan.ih, plan.iw, plan.cin,
-                      ph.OYn, ph.OXn, plan.sy, plan.sx, ph.oy0, ph.ox0, 1, 1, B, plan.cout_magic)
+                      ph.OYn, ph.OXn, plan.sy, plan.sx, ph.oy0, ph.ox0, 1, 1, B, plan.cout_magic, addend=addend)
     return dx
 
 

@@ -88,13 +88,29 @@ def _deliver_wgrad(param, x, dy, plan):
     return out
 
 
+class GradSlot:
+    """Side channel for the gradient of a residual (identity) connection.
+
+    In ``out = act(bn(conv3(h)) + x)`` with ``h = f(conv1(x))`` the gradient of ``x`` is
+    ``dgrad(conv1) + g`` where ``g`` is the masked incoming gradient.  Letting autograd sum the two
+    costs a full read-read-write pass over the activation; instead the layer that consumes the
+    residual parks ``g`` here during its backward and the layer that first consumed ``x`` adds it
+    inside the epilogue of its data-gradient kernel.  Dependencies guarantee the order: the
+    residual consumer's backward always runs before the backward of anything upstream of it."""
+
+    __slots__ = ("grad",)
+
+    def __init__(self):
+        self.grad = None
+
+
 # ----------------------------------------------------------------------------
 # conv + batch-norm (+ residual) (+ ReLU)
 # ----------------------------------------------------------------------------
 class _ConvBnActFn(Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, plan, run_mean, run_var, eps, momentum, relu, training,
-                params):
+                params, res_slot=None, in_slot=None):
         need_grad = any(ctx.needs_input_grad)
         y, part = cv.conv_fwd(x, weight, plan, want_stats=training)
         M = y.numel() // plan.cout
@@ -107,6 +123,7 @@ class _ConvBnActFn(Function):
         ctx.plan, ctx.relu, ctx.training = plan, relu, training
         ctx.has_res = residual is not None
         ctx.params = params  # (weight_param, gamma_param, beta_param) python objects
+        ctx.res_slot, ctx.in_slot = res_slot, in_slot
         if need_grad:
             # the ReLU mask is recomputed from y when nothing was added before the activation
             keep_z = relu and (residual is not None or not training)
@@ -120,6 +137,9 @@ class _ConvBnActFn(Function):
         wparam, gparam, bparam = ctx.params
         dz = dz.contiguous()
         want_dres = ctx.has_res and ctx.needs_input_grad[4]
+        addend = None
+        if ctx.in_slot is not None:
+            addend, ctx.in_slot.grad = ctx.in_slot.grad, None
         if ctx.training:
             dy, dres, dgamma, dbeta = K.bn_backward(dz, y, z, mean, invstd, gamma, ctx.relu, want_dres,
                                                     scale=scale, shift=shift)
@@ -138,12 +158,14 @@ class _ConvBnActFn(Function):
         if ctx.needs_input_grad[3]:
             gb = _deliver_small(bparam, dbeta) if bparam is not None else dbeta
         if ctx.needs_input_grad[0]:
-            gx = cv.conv_dgrad(dy, weight, plan)
-        return gx, gw, gg, gb, dres, None, None, None, None, None, None, None, None
+            gx = cv.conv_dgrad(dy, weight, plan, addend=addend)
+        if ctx.res_slot is not None and dres is not None:
+            ctx.res_slot.grad, dres = dres, None  # picked up by the upstream layer's dgrad epilogue
+        return gx, gw, gg, gb, dres, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, eps, momentum, relu, training,
-                residual=None):
+                residual=None, residual_grad_slot=None, input_grad_slot=None):
     """``act(bn(conv(x, weight)) + residual)``; batch statistics when ``training``."""
     kh, kw = weight.shape[1], weight.shape[2]
     sy, sx = stride
@@ -158,8 +180,10 @@ def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, e
             z = z + residual
         return torch.relu(z) if relu else z
     plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], weight.shape[0], kh, kw, sy, sx, pads, x.device)
+    if input_grad_slot is not None and (plan.dgrad_needs_zero or not x.requires_grad):
+        raise ValueError("input_grad_slot needs an input that requires grad and a dgrad that writes every pixel")
     return _ConvBnActFn.apply(x, weight, gamma, beta, residual, plan, run_mean, run_var, eps, momentum, relu,
-                              training, (weight, gamma, beta))
+                              training, (weight, gamma, beta), residual_grad_slot, input_grad_slot)
 
 
 # ----------------------------------------------------------------------------

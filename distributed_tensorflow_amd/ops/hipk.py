@@ -23,7 +23,7 @@ c_float = C.c_float
 
 class ConvArgs(C.Structure):
     _fields_ = [
-        ("x", c_void), ("w", c_void), ("y", c_void), ("bias", c_void), ("stats", c_void),
+        ("x", c_void), ("w", c_void), ("y", c_void), ("bias", c_void), ("addend", c_void), ("stats", c_void),
         ("zero", c_void), ("taps", c_void),
         ("IH", c_int), ("IW", c_int), ("Cin", c_int),
         ("OH", c_int), ("OW", c_int), ("Cout", c_int),
