@@ -68,7 +68,8 @@ def main():
     if args.model == "inception_v3_head":
         opt, lr, okw = "adam", 1e-3, {}
     else:
-        opt, lr, okw = "momentum", 0.1 * batch * world / 256.0, {"momentum": 0.9, "weight_decay": 1e-4}
+        # a fixed synthetic batch with random labels: a small constant rate keeps the loss finite at any world size
+        opt, lr, okw = "momentum", 0.02, {"momentum": 0.9, "weight_decay": 1e-4}
     engine = DataParallelEngine(model, mode=args.mode, optimizer=opt, lr=lr, opt_kwargs=okw,
                                 bucket_mb=args.bucket_mb, staleness=args.staleness)
 

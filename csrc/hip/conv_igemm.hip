@@ -45,6 +45,7 @@ struct ConvArgs {
   unsigned cin_magic;  // ceil(2^32 / Cin)
   int relu;
   int dense_out;       // output pixel index == m (no stride/offset mapping)
+  int pointwise;       // 1x1, stride 1, no padding, dense output: input pixel index == m
 };
 
 #define MAX_TAPS 64
@@ -56,7 +57,9 @@ __device__ __forceinline__ int swz_of_row(int row) {
   return (row / R) & (S - 1);
 }
 
-template <int BM, int BN, int BK>
+// EPI selects the epilogue at compile time: 0 = plain store (data-gradient, no statistics),
+// 1 = batch-norm partial statistics, 2 = bias (+ optional ReLU).
+template <int BM, int BN, int BK, int EPI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   constexpr int S = BK / 8;            // 16-byte slots per LDS row
   constexpr int ROWB = BK * 2;         // bytes per LDS row
@@ -95,10 +98,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   const bf16* abase[NA];
   int aiy[NA], aix[NA];
   const int opix = p.OYn * p.OXn;
+  // 1x1 / stride-1 / unpadded: input pixel == output pixel == m, no decode and no bounds checks
+  const bool pointwise = p.pointwise != 0;
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     int m = m0 + (i * 4 + wid) * RPI + row_in_inst;
-    if (m < p.M) {
+    if (pointwise) {
+      aiy[i] = m < p.M ? 0 : -(1 << 24);
+      aix[i] = 0;
+      abase[i] = p.x + (size_t)(m < p.M ? m : 0) * p.Cin;
+    } else if (m < p.M) {
       int b = m / opix;
       int rem = m - b * opix;
       int oy = rem / p.OXn;
@@ -128,17 +137,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     char* sb = sa + BM * ROWB;
     const int kc8 = kt * BK + cslot * 8;
     const bool kvalid = kc8 < p.K;
-    const int tap = (int)__umulhi((unsigned)kc8, p.cin_magic);
-    const int ci = kc8 - tap * p.Cin;
-    const int tp = kvalid ? lds_taps[tap] : 0;
-    const int dy = tp >> 16;
-    const int dx = (int)(short)(tp & 0xffff);
+    if (pointwise) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      int iy = aiy[i] + dy, ix = aix[i] + dx;
-      bool ok = kvalid && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-      const bf16* src = ok ? abase[i] + ((size_t)(iy * p.IW + ix) * p.Cin + ci) : p.zero;
-      glds16(src, sa + (i * 4 + wid) * 1024);
+      for (int i = 0; i < NA; ++i) {
+        const bf16* src = (kvalid && aiy[i] == 0) ? abase[i] + kc8 : p.zero;
+        glds16(src, sa + (i * 4 + wid) * 1024);
+      }
+    } else {
+      const int tap = (int)__umulhi((unsigned)kc8, p.cin_magic);
+      const int ci = kc8 - tap * p.Cin;
+      const int tp = kvalid ? lds_taps[tap] : 0;
+      const int dy = tp >> 16;
+      const int dx = (int)(short)(tp & 0xffff);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        int iy = aiy[i] + dy, ix = aix[i] + dx;
+        bool ok = kvalid && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const bf16* src = ok ? abase[i] + ((size_t)(iy * p.IW + ix) * p.Cin + ci) : p.zero;
+        glds16(src, sa + (i * 4 + wid) * 1024);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -216,23 +233,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   for (int nt = 0; nt < NT; ++nt) {
     const int co = n0 + wc * WN + nt * 32 + colq;
     float bias = 0.f;
-    if (p.bias != nullptr && co < p.Cout) bias = p.bias[co];
+    if (EPI == 2 && p.bias != nullptr && co < p.Cout) bias = p.bias[co];
+    const bool relu = EPI == 2 && p.relu != 0;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        float v = acc[mt][nt][j] + bias;
-        if (p.relu) v = fmaxf(v, 0.f);
-        bf16 hv = (bf16)v;
-        float vr = (float)hv;
-        s1 += vr;
-        s2 += vr * vr;
+        float v = acc[mt][nt][j];
+        if (EPI == 2) {
+          v += bias;
+          if (relu) v = fmaxf(v, 0.f);
+        }
+        if (EPI == 1) {  // statistics of the fp32 accumulators (rounding to bf16 is unbiased)
+          s1 += v;
+          s2 += v * v;
+        }
         int r = mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * khalf;
-        *(bf16*)(ep + r * EP_PITCH + (nt * 32 + colq) * 2) = hv;
+        *(bf16*)(ep + r * EP_PITCH + (nt * 32 + colq) * 2) = (bf16)v;
       }
     }
-    if (p.stats != nullptr) {
+    if (EPI == 1) {
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       if (khalf == 0 && co < p.Cout) {
@@ -274,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   }
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int EPI>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   constexpr int ROWB = BK * 2;
   constexpr int STAGE = (BM + BN) * ROWB;
@@ -283,11 +304,19 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   unsigned mtiles = (a.M + BM - 1) / BM, ntiles = (a.Cout + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, EPI>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK>), dim3(mtiles * ntiles), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, EPI>), dim3(mtiles * ntiles), dim3(256), lds, stream, a);
   return (int)hipGetLastError();
+}
+
+template <int BM, int BN, int BK>
+static int launch_conv_epi(const ConvArgs& a, hipStream_t stream) {
+  if (a.stats != nullptr) return launch_conv<BM, BN, BK, 1>(a, stream);
+  if (a.bias != nullptr || a.relu) return launch_conv<BM, BN, BK, 2>(a, stream);
+  return launch_conv<BM, BN, BK, 0>(a, stream);
 }
 
 // Number of partial-statistics rows the kernel writes for a given M and BM.
@@ -296,17 +325,16 @@ extern "C" int dtfa_conv_stats_rows(int M, int bm) { return ((M + bm - 1) / bm) 
 extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, hipStream_t stream) {
   if (a->Cin % 8 != 0 || a->Cout % 8 != 0 || a->T > MAX_TAPS || a->T < 1) return -1;
   if (a->K != a->T * a->Cin || a->K >= (1 << 16)) return -2;
+  if (a->stats != nullptr && a->bias != nullptr) return -4;
   if (a->M <= 0) return 0;
 #define CASE(BM_, BN_, BK_) \
-  if (bm == BM_ && bn == BN_ && bk == BK_) return launch_conv<BM_, BN_, BK_>(*a, stream);
+  if (bm == BM_ && bn == BN_ && bk == BK_) return launch_conv_epi<BM_, BN_, BK_>(*a, stream);
   CASE(128, 128, 32)
   CASE(128, 64, 32)
   CASE(64, 64, 32)
-  CASE(256, 128, 32)
   CASE(128, 128, 64)
   CASE(128, 64, 64)
   CASE(64, 64, 64)
-  CASE(256, 128, 64)
 #undef CASE
   return -3;
 }

@@ -27,6 +27,7 @@ struct WgradArgs {
   int T, M, K;
   unsigned cin_magic;
   int ktiles_per_split;
+  int splits;
   // decomposition of one k-tile step (BKP pixels) into (images, rows, cols)
   int step_b, step_y, step_x;
 };
@@ -64,10 +65,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;
 
+  // 1-D grid ordered so that all output tiles of one pixel split share blockIdx % 8, i.e. (under the
+  // round-robin block->XCD dispatch) one XCD and its L2: they re-read the same dY / X rows.
+  //   id = ((split / 8) * tiles + tile) * 8 + split % 8
   const unsigned ntiles = (p.K + BNW - 1) / BNW;
-  const unsigned tile_m = blockIdx.x / ntiles, tile_n = blockIdx.x % ntiles;
+  const unsigned mtiles = (p.Cout + BMW - 1) / BMW;
+  const unsigned tiles = ntiles * mtiles;
+  const unsigned grp = blockIdx.x / 8, lane8 = blockIdx.x % 8;
+  const unsigned tile = grp % tiles;
+  const int split = (int)((grp / tiles) * 8 + lane8);
+  if (split >= p.splits) return;
+  const unsigned tile_m = tile / ntiles, tile_n = tile % ntiles;
   const int co0 = tile_m * BMW, n0 = tile_n * BNW;
-  const int split = blockIdx.y;
 
   if (tid < p.T) lds_taps[tid] = p.taps[tid];
   __syncthreads();
@@ -160,9 +169,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
       const char* sa = lds_tiles + cur * STAGE;
       const char* sb = sa + BKP * RBA;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        s16x8 af[MT], bfr[NT];
+      auto load_frags = [&](int ks, s16x8* af, s16x8* bfr) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const int krow = ks * 16 + tr_k + 4 * r;
@@ -181,12 +188,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             bfr[nt][4 * r + 2] = v[2]; bfr[nt][4 * r + 3] = v[3];
           }
         }
+      };
+      s16x8 af[2][MT], bfr[2][NT];
+      load_frags(0, af[0], bfr[0]);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int c = ks & 1;
+        if (ks + 1 < KS) load_frags(ks + 1, af[c ^ 1], bfr[c ^ 1]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, af[mt]), __builtin_bit_cast(bf16x8, bfr[nt]), acc[mt][nt], 0, 0, 0);
+                __builtin_bit_cast(bf16x8, af[c][mt]), __builtin_bit_cast(bf16x8, bfr[c][nt]), acc[mt][nt], 0, 0, 0);
       }
       wait_vmcnt0();
       __syncthreads();
@@ -261,7 +275,8 @@ static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t stream) {
     hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, BKP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, BKP>), dim3(mt * nt, splits), dim3(256), lds, stream, a);
+  unsigned split_groups = (splits + 7) / 8;
+  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, BKP>), dim3(mt * nt * split_groups * 8), dim3(256), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -270,6 +285,7 @@ extern "C" int dtfa_conv_wgrad(WgradArgs* a, int bmw, int bnw, int bkp, int spli
   if (a->K != a->T * a->Cin || a->K >= (1 << 16) || splits < 1) return -2;
   int kt_total = (a->M + bkp - 1) / bkp;
   a->ktiles_per_split = (kt_total + splits - 1) / splits;
+  a->splits = splits;
   int opix = a->OH * a->OW;
   a->step_b = bkp / opix;
   int rem = bkp % opix;

@@ -133,6 +133,7 @@ class ConvPlan:
                     len(taps), oyn, oxn, ph, pw))
         self.cin_magic = _magic(cin)
         self.cout_magic = _magic(cout)
+        self.is_pointwise = kh == 1 and kw == 1 and sy == 1 and sx == 1 and not any(self.pads)
 
 
 _plans: Dict[tuple, ConvPlan] = {}
@@ -150,7 +151,7 @@ def get_plan(ih, iw, cin, cout, kh, kw, sy, sx, pads, device) -> ConvPlan:
 # --------------------------------------------------------------------------
 # tile selection
 # --------------------------------------------------------------------------
-_FWD_TILES = {(128, 128), (128, 64), (64, 64), (256, 128)}
+_FWD_TILES = {(128, 128), (128, 64), (64, 64)}
 
 
 def _env_tile(name: str):
@@ -196,7 +197,7 @@ def pick_wgrad_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
 # launches
 # --------------------------------------------------------------------------
 def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, osx, oy0, ox0, isy, isx, B,
-                  cin_magic, bias=None, relu=False, stats=False, addend=None):
+                  cin_magic, bias=None, relu=False, stats=False, addend=None, zero_taps=False):
     M = B * oyn * oxn
     K = T * cin
     bm, bn, bk = pick_fwd_tile(M, cout, K)
@@ -221,6 +222,9 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     a.cin_magic = cin_magic
     a.relu = 1 if relu else 0
     a.dense_out = 1 if (osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow) else 0
+    # 1x1 / stride 1 / no padding: input pixel index == output pixel index, the kernel skips the pixel decode
+    a.pointwise = 1 if (zero_taps and a.dense_out and T == 1 and isy == 1 and isx == 1
+                        and ih == oyn and iw == oxn) else 0
     hipk.check(L.dtfa_conv_igemm(C.byref(a), bm, bn, bk, hipk.stream()), "conv_igemm %dx%dx%d" % (bm, bn, bk))
     return part
 
@@ -245,7 +249,8 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
         raise ValueError("too many output pixels for 32-bit row indices")
     y = torch.empty((B, plan.oh, plan.ow, plan.cout), dtype=torch.bfloat16, device=x.device)
     part = _launch_igemm(x, w, y, plan.fwd_taps, plan.T, plan.ih, plan.iw, plan.cin, plan.oh, plan.ow, plan.cout,
-                         plan.oh, plan.ow, 1, 1, 0, 0, plan.sy, plan.sx, B, plan.cin_magic, bias, relu, want_stats)
+                         plan.oh, plan.ow, 1, 1, 0, 0, plan.sy, plan.sx, B, plan.cin_magic, bias, relu, want_stats,
+                         zero_taps=plan.is_pointwise)
     return y, part
 
 
@@ -275,7 +280,8 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Option
         hipk.check(L.dtfa_weight_permute(w.data_ptr(), wd.data_ptr(), ph.src_tap.data_ptr(), plan.cout, plan.T,
                                          plan.cin, ph.T, hipk.stream()), "weight_permute")
         _launch_igemm(dy, wd, dx, ph.taps, ph.T, plan.oh, plan.ow, plan.cout, plan.ih, plan.iw, plan.cin,
-                      ph.OYn, ph.OXn, plan.sy, plan.sx, ph.oy0, ph.ox0, 1, 1, B, plan.cout_magic, addend=addend)
+                      ph.OYn, ph.OXn, plan.sy, plan.sx, ph.oy0, ph.ox0, 1, 1, B, plan.cout_magic, addend=addend,
+                      zero_taps=plan.is_pointwise)
     return dx
 
 

@@ -140,8 +140,19 @@ class _ConvBnActFn(Function):
         addend = None
         if ctx.in_slot is not None:
             addend, ctx.in_slot.grad = ctx.in_slot.grad, None
+        direct = False
         if ctx.training:
+            # per-channel gradients go straight into the flat gradient buffer when both parameters live there
+            g_mg = getattr(gparam, "main_grad", None) if (gamma is not None and ctx.needs_input_grad[2]) else None
+            b_mg = getattr(bparam, "main_grad", None) if ctx.needs_input_grad[3] else None
+            filled = getattr(bparam, "_grad_filled", False)
+            direct = (b_mg is not None and b_mg.dtype == torch.float32
+                      and (gamma is None or (g_mg is not None and g_mg.dtype == torch.float32
+                                             and getattr(gparam, "_grad_filled", False) == filled)))
             dy, dres, dgamma, dbeta = K.bn_backward(dz, y, z, mean, invstd, gamma, ctx.relu, want_dres,
+                                                    dgamma_out=g_mg if direct else None,
+                                                    dbeta_out=b_mg if direct else None,
+                                                    accumulate=filled if direct else False,
                                                     scale=scale, shift=shift)
         else:
             g = K.relu_bwd(dz, z) if ctx.relu else dz
@@ -153,10 +164,15 @@ class _ConvBnActFn(Function):
         gx = gw = gg = gb = None
         if ctx.needs_input_grad[1]:
             gw = _deliver_wgrad(wparam if wparam is not None else weight, x, dy, plan)
-        if gamma is not None and ctx.needs_input_grad[2]:
-            gg = _deliver_small(gparam if gparam is not None else gamma, dgamma)
-        if ctx.needs_input_grad[3]:
-            gb = _deliver_small(bparam, dbeta) if bparam is not None else dbeta
+        if direct:
+            if gamma is not None:
+                _notify(gparam)
+            _notify(bparam)
+        else:
+            if gamma is not None and ctx.needs_input_grad[2]:
+                gg = _deliver_small(gparam if gparam is not None else gamma, dgamma)
+            if ctx.needs_input_grad[3]:
+                gb = _deliver_small(bparam, dbeta) if bparam is not None else dbeta
         if ctx.needs_input_grad[0]:
             gx = cv.conv_dgrad(dy, weight, plan, addend=addend)
         if ctx.res_slot is not None and dres is not None:

@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
         ("osy", c_int), ("osx", c_int), ("oy0", c_int), ("ox0", c_int),
         ("isy", c_int), ("isx", c_int),
         ("T", c_int), ("M", c_int), ("K", c_int),
-        ("cin_magic", C.c_uint), ("relu", c_int), ("dense_out", c_int),
+        ("cin_magic", C.c_uint), ("relu", c_int), ("dense_out", c_int), ("pointwise", c_int),
     ]
 
 
@@ -42,7 +42,7 @@ class WgradArgs(C.Structure):
         ("OH", c_int), ("OW", c_int), ("Cout", c_int),
         ("isy", c_int), ("isx", c_int),
         ("T", c_int), ("M", c_int), ("K", c_int),
-        ("cin_magic", C.c_uint), ("ktiles_per_split", c_int),
+        ("cin_magic", C.c_uint), ("ktiles_per_split", c_int), ("splits", c_int),
         ("step_b", c_int), ("step_y", c_int), ("step_x", c_int),
     ]
 

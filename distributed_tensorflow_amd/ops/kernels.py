@@ -123,9 +123,14 @@ def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, d
                                       part.data_ptr(), M, Cc, mode, hipk.stream()), "bn_bwd_partials")
     part = reduce_partials(part)
     coef = torch.empty((3, Cc), dtype=F32, device=y.device)
-    dgamma = dgamma_out if dgamma_out is not None else torch.empty(Cc, dtype=F32, device=y.device)
+    for o in (dgamma_out, dbeta_out):
+        if o is not None and (o.dtype != F32 or o.numel() != Cc or not o.is_contiguous()):
+            raise ValueError("bad per-channel gradient output buffer")
+    acc = 1 if (accumulate and dbeta_out is not None) else 0
+    # gamma-less layers still produce a dgamma; it lands in scratch so accumulation never touches a real buffer
+    dgamma = dgamma_out if dgamma_out is not None else torch.zeros(Cc, dtype=F32, device=y.device) if acc \
+        else torch.empty(Cc, dtype=F32, device=y.device)
     dbeta = dbeta_out if dbeta_out is not None else torch.empty(Cc, dtype=F32, device=y.device)
-    acc = 1 if (accumulate and dgamma_out is not None) else 0
     hipk.check(L.dtfa_bn_bwd_finalize(part.data_ptr(), part.shape[0], Cc, float(M), hipk.ptr(gamma),
                                       mean.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                       coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), acc,
