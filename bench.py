@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default depends on the model)")
     ap.add_argument("--bucket_mb", type=float, default=32.0)
     ap.add_argument("--staleness", type=int, default=1)
+    ap.add_argument("--hip_graph", type=int, default=0,
+                    help="1: record the whole step (fwd, bwd, collectives, optimizer) in a HIP graph and replay it")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,6 +96,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.hip_graph:
+        from distributed_tensorflow_amd.train.graph import StepGraph
+
+        def loss_fn(im, lb):
+            out = model(im)
+            logits, reg = out if isinstance(out, tuple) else (out, None)
+            loss, _, _, _ = F.softmax_xent(logits, lb, 5)
+            return (loss if reg is None else loss + reg), loss
+
+        for _ in range(2):  # eager steps create plans, workspaces and communicators before the capture
+            step()
+        sg = StepGraph(engine, loss_fn, images, labels)
+
+        def step():  # noqa: F811
+            return sg.run(images, labels)[1]
+
     for _ in range(args.warmup):
         step()
     sync()
@@ -124,7 +142,7 @@ def main():
             "final_loss": round(float(loss.item()), 4),
             "config": {"model": args.model, "global_batch": batch * world, "per_gpu_batch": batch,
                        "image_size": size, "num_classes": 5, "parallelism": "dp%d" % world, "mode": args.mode,
-                       "optimizer": opt},
+                       "optimizer": opt, "hip_graph": bool(args.hip_graph)},
         }), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -50,30 +50,53 @@ extern "C" int dtfa_partial_reduce(const float* in, float* out, int R, int NV, i
 // and updates running_mean / running_var in place:
 //   running = running * (1 - momentum) + batch * momentum  (unbiased variance)
 // ----------------------------------------------------------------------------
-// Block = 32 channels x 8 row lanes; the row lanes are combined through LDS in a
-// fixed order.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const float* __restrict__ part, int R, int C, float count, float eps, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-    float* __restrict__ shift, float* __restrict__ run_mean, float* __restrict__ run_var, float momentum) {
-  __shared__ double red[2][8][32];
+// Sum the two value planes of part[R][2][C] for channel c with RL row lanes (block = 32 channels x RL
+// lanes); lanes are combined through LDS in a fixed order, so the result depends only on (R, RL).
+// Returns true for the one thread per channel that holds the totals.
+template <int RL>
+__device__ inline bool reduce_part_rows(const float* __restrict__ part, int R, int C, int c, double& s, double& ss) {
+  __shared__ double red[2][RL][32];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx;
-  double s = 0.0, ss = 0.0;
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
   if (c < C) {
-    for (int r = ty; r < R; r += 8) {
-      s += (double)part[((size_t)r * 2) * C + c];
-      ss += (double)part[((size_t)r * 2 + 1) * C + c];
+    int r = ty;
+    for (; r + RL < R; r += 2 * RL) {
+      float p0 = part[((size_t)r * 2) * C + c], q0 = part[((size_t)r * 2 + 1) * C + c];
+      float p1 = part[((size_t)(r + RL) * 2) * C + c], q1 = part[((size_t)(r + RL) * 2 + 1) * C + c];
+      a0 += (double)p0;
+      b0 += (double)q0;
+      a1 += (double)p1;
+      b1 += (double)q1;
+    }
+    if (r < R) {
+      a0 += (double)part[((size_t)r * 2) * C + c];
+      b0 += (double)part[((size_t)r * 2 + 1) * C + c];
     }
   }
-  red[0][ty][tx] = s;
-  red[1][ty][tx] = ss;
+  red[0][ty][tx] = a0 + a1;
+  red[1][ty][tx] = b0 + b1;
   __syncthreads();
-  if (ty != 0 || c >= C) return;
-  for (int t = 1; t < 8; ++t) {
+  if (ty != 0 || c >= C) return false;
+  s = 0.0;
+  ss = 0.0;
+  for (int t = 0; t < RL; ++t) {
     s += red[0][t][tx];
     ss += red[1][t][tx];
   }
+  return true;
+}
+
+// Row-lane count of the finalize kernels: 8 lanes up to 64 partial rows, 32 lanes (1024 threads) above.
+static inline int finalize_lanes(int R) { return R <= 64 ? 8 : 32; }
+
+template <int RL>
+__global__ __launch_bounds__(32 * RL) void bn_finalize_kernel(
+    const float* __restrict__ part, int R, int C, float count, float eps, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+    float* __restrict__ shift, float* __restrict__ run_mean, float* __restrict__ run_var, float momentum) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  double s, ss;
+  if (!reduce_part_rows<RL>(part, R, C, c, s, ss)) return;
   double mu = s / count;
   double var = ss / count - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -95,8 +118,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
 extern "C" int dtfa_bn_finalize(const float* part, int R, int C, float count, float eps, const float* gamma,
                                 const float* beta, float* mean, float* invstd, float* scale, float* shift,
                                 float* run_mean, float* run_var, float momentum, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part, R, C, count, eps, gamma,
-                     beta, mean, invstd, scale, shift, run_mean, run_var, momentum);
+  if (finalize_lanes(R) == 8)
+    hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3((C + 31) / 32), dim3(256), 0, st, part, R, C, count, eps, gamma,
+                       beta, mean, invstd, scale, shift, run_mean, run_var, momentum);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3((C + 31) / 32), dim3(1024), 0, st, part, R, C, count, eps,
+                       gamma, beta, mean, invstd, scale, shift, run_mean, run_var, momentum);
   return (int)hipGetLastError();
 }
 
@@ -126,10 +153,13 @@ extern "C" int dtfa_bn_eval_coeffs(int C, float eps, const float* gamma, const f
 template <bool RELU, bool RES>
 __global__ void bn_apply_kernel(const bf16* __restrict__ y, const bf16* __restrict__ res, bf16* __restrict__ z,
                                 const float* __restrict__ scale, const float* __restrict__ shift, size_t nvec,
-                                int C) {
+                                int C, int ldz) {
+  // ldz: elements between consecutive output rows (== C for a dense output, larger when z is a channel
+  // slice of a wider NHWC tensor, which is how branch outputs land in a concatenation without a copy)
   const int cvec = C >> 3;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-    int c0 = (int)(i % cvec) << 3;
+    const size_t row = i / cvec;
+    int c0 = (int)(i - row * cvec) << 3;
     bf16x8 v = *(const bf16x8*)(y + i * 8);
     bf16x8 r;
     if (RES) r = *(const bf16x8*)(res + i * 8);
@@ -145,20 +175,20 @@ __global__ void bn_apply_kernel(const bf16* __restrict__ y, const bf16* __restri
       if (RELU) f = fmaxf(f, 0.f);
       o[j] = (bf16)f;
     }
-    *(bf16x8*)(z + i * 8) = o;
+    *(bf16x8*)(z + row * ldz + c0) = o;
   }
 }
 
 extern "C" int dtfa_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
-                             long long M, int C, int relu, hipStream_t st) {
-  if (C % 8) return -1;
+                             long long M, int C, int ldz, int relu, hipStream_t st) {
+  if (C % 8 || ldz % 8 || ldz < C) return -1;
   size_t nvec = (size_t)M * C / 8;
   if (nvec == 0) return 0;
   unsigned blocks = (unsigned)((nvec + 255) / 256);
   if (blocks > 8192) blocks = 8192;
 #define L(R_, S_)                                                                                          \
   hipLaunchKernelGGL((bn_apply_kernel<R_, S_>), dim3(blocks), dim3(256), 0, st, (const bf16*)y,            \
-                     (const bf16*)res, (bf16*)z, scale, shift, nvec, C)
+                     (const bf16*)res, (bf16*)z, scale, shift, nvec, C, ldz)
   if (relu && res) L(true, true);
   else if (relu) L(true, false);
   else if (res) L(false, true);
@@ -322,29 +352,15 @@ extern "C" int dtfa_bn_bwd_partials(const void* dz, const void* y, const void* z
 //   dy = gscale * (g - c1 - xhat*c2),  c1 = sum g / M, c2 = sum g*xhat / M
 //      = ca * g + cb * y + cc
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+template <int RL>
+__global__ __launch_bounds__(32 * RL) void bn_bwd_finalize_kernel(
     const float* __restrict__ part, int R, int C, float count, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc,
     int accumulate) {
-  __shared__ double red[2][8][32];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx;
-  double s = 0.0, sx = 0.0;
-  if (c < C) {
-    for (int r = ty; r < R; r += 8) {
-      s += (double)part[((size_t)r * 2) * C + c];
-      sx += (double)part[((size_t)r * 2 + 1) * C + c];
-    }
-  }
-  red[0][ty][tx] = s;
-  red[1][ty][tx] = sx;
-  __syncthreads();
-  if (ty != 0 || c >= C) return;
-  for (int t = 1; t < 8; ++t) {
-    s += red[0][t][tx];
-    sx += red[1][t][tx];
-  }
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  double s, sx;
+  if (!reduce_part_rows<RL>(part, R, C, c, s, sx)) return;
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
   float c1 = (float)(s / count), c2 = (float)(sx / count);
@@ -358,8 +374,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
 extern "C" int dtfa_bn_bwd_finalize(const float* part, int R, int C, float count, const float* gamma,
                                     const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                     float* ca, float* cb, float* cc, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part, R, C, count, gamma,
-                     mean, invstd, dgamma, dbeta, ca, cb, cc, accumulate);
+  if (finalize_lanes(R) == 8)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, dim3((C + 31) / 32), dim3(256), 0, st, part, R, C, count, gamma,
+                       mean, invstd, dgamma, dbeta, ca, cb, cc, accumulate);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<32>, dim3((C + 31) / 32), dim3(1024), 0, st, part, R, C, count, gamma,
+                       mean, invstd, dgamma, dbeta, ca, cb, cc, accumulate);
   return (int)hipGetLastError();
 }
 

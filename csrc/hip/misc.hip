@@ -48,8 +48,16 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
   return x;
 }
 
+// ``step`` (optional) points at a device-resident step counter that is folded into the seed, so a
+// launch recorded once in a HIP graph still draws a fresh mask on every replay.
 __global__ void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t n, unsigned seed_lo,
-                               unsigned seed_hi, unsigned thresh16, float scale) {
+                               unsigned seed_hi, const unsigned long long* __restrict__ step, unsigned thresh16,
+                               float scale) {
+  if (step != nullptr) {
+    unsigned long long t = step[0];
+    seed_lo ^= mix32((unsigned)t * 0x85ebca6bu + 0x27d4eb2fu);
+    seed_hi += mix32((unsigned)(t >> 32) ^ 0xc2b2ae35u) + (unsigned)t;
+  }
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n;
        i += (size_t)gridDim.x * blockDim.x * 2) {
     unsigned h = mix32((unsigned)(i >> 1) * 0x9e3779b9u + seed_lo);
@@ -65,8 +73,8 @@ __global__ void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
 }
 
 // rate = drop probability; the same call with dy as input is the backward.
-extern "C" int dtfa_dropout(const void* x, void* y, long long n, unsigned long long seed, float rate,
-                            hipStream_t st) {
+extern "C" int dtfa_dropout(const void* x, void* y, long long n, unsigned long long seed,
+                            const unsigned long long* step, float rate, hipStream_t st) {
   if (n <= 0) return 0;
   if (!(rate >= 0.f) || rate >= 1.f) return -1;
   unsigned thresh = (unsigned)(rate * 65536.f + 0.5f);
@@ -75,7 +83,7 @@ extern "C" int dtfa_dropout(const void* x, void* y, long long n, unsigned long l
   size_t blocks = (pairs + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)y, (size_t)n,
-                     (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), thresh, scale);
+                     (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), step, thresh, scale);
   return (int)hipGetLastError();
 }
 

@@ -32,6 +32,31 @@ def _c(cin, cout, k, scope, stride=1, padding="SAME", **kw):
     return ConvBnAct(cin, cout, k, stride, padding, tf_scope=scope, **_BN, **kw)
 
 
+def _concat(block: nn.Module, x, hw, parts):
+    """Channel concatenation of parallel branches.
+
+    ``parts`` is a list of ``(channels, producer)``; ``producer(out)`` computes one branch and, when
+    ``out`` (a channel slice of the result) is given, has its last layer write into it.  With nothing
+    requiring grad (the frozen trunk of the flower model) the branches write straight into one
+    buffer; otherwise the outputs are joined with ``torch.cat`` so autograd sees ordinary tensors."""
+    if not F.concat_plan(x, *block.parameters()):
+        return torch.cat([prod(None) for _, prod in parts], dim=3)
+    buf = torch.empty((x.shape[0], hw[0], hw[1], sum(c for c, _ in parts)), dtype=x.dtype, device=x.device)
+    off = 0
+    for c, prod in parts:
+        sl = buf[..., off:off + c]
+        r = prod(sl)
+        if r.data_ptr() != sl.data_ptr():  # producer without a fused writer (pooling branch)
+            sl.copy_(r)
+        off += c
+    return buf
+
+
+def _reduced(x):
+    """Spatial size after a 3x3 / stride 2 / VALID layer."""
+    return (x.shape[1] - 3) // 2 + 1, (x.shape[2] - 3) // 2 + 1
+
+
 class _Mixed5(nn.Module):
     """35x35 blocks Mixed_5b/5c/5d."""
 
@@ -47,12 +72,12 @@ class _Mixed5(nn.Module):
         self.b3 = _c(cin, pool_ch, 1, s + "/Branch_3/Conv2d_0b_1x1")
 
     def forward(self, x):
-        return torch.cat([
-            self.b0(x),
-            self.b1b(self.b1a(x)),
-            self.b2c(self.b2b(self.b2a(x))),
-            self.b3(F.avg_pool(x, (3, 3), (1, 1), "SAME")),
-        ], dim=3)
+        return _concat(self, x, x.shape[1:3], [
+            (64, lambda o: self.b0(x, out=o)),
+            (64, lambda o: self.b1b(self.b1a(x), out=o)),
+            (96, lambda o: self.b2c(self.b2b(self.b2a(x)), out=o)),
+            (self.b3.weight.shape[0], lambda o: self.b3(F.avg_pool(x, (3, 3), (1, 1), "SAME"), out=o)),
+        ])
 
 
 class _Mixed6a(nn.Module):
@@ -65,11 +90,11 @@ class _Mixed6a(nn.Module):
         self.b1c = _c(96, 96, 3, s + "/Branch_1/Conv2d_1a_1x1", stride=2, padding="VALID")
 
     def forward(self, x):
-        return torch.cat([
-            self.b0(x),
-            self.b1c(self.b1b(self.b1a(x))),
-            F.max_pool(x, (3, 3), (2, 2), "VALID"),
-        ], dim=3)
+        return _concat(self, x, _reduced(x), [
+            (384, lambda o: self.b0(x, out=o)),
+            (96, lambda o: self.b1c(self.b1b(self.b1a(x)), out=o)),
+            (x.shape[3], lambda o: F.max_pool(x, (3, 3), (2, 2), "VALID")),
+        ])
 
 
 class _Mixed6(nn.Module):
@@ -90,12 +115,12 @@ class _Mixed6(nn.Module):
         self.b3 = _c(cin, 192, 1, s + "/Branch_3/Conv2d_0b_1x1")
 
     def forward(self, x):
-        return torch.cat([
-            self.b0(x),
-            self.b1c(self.b1b(self.b1a(x))),
-            self.b2e(self.b2d(self.b2c(self.b2b(self.b2a(x))))),
-            self.b3(F.avg_pool(x, (3, 3), (1, 1), "SAME")),
-        ], dim=3)
+        return _concat(self, x, x.shape[1:3], [
+            (192, lambda o: self.b0(x, out=o)),
+            (192, lambda o: self.b1c(self.b1b(self.b1a(x)), out=o)),
+            (192, lambda o: self.b2e(self.b2d(self.b2c(self.b2b(self.b2a(x)))), out=o)),
+            (192, lambda o: self.b3(F.avg_pool(x, (3, 3), (1, 1), "SAME"), out=o)),
+        ])
 
 
 class _Mixed7a(nn.Module):
@@ -110,11 +135,11 @@ class _Mixed7a(nn.Module):
         self.b1d = _c(192, 192, 3, s + "/Branch_1/Conv2d_1a_3x3", stride=2, padding="VALID")
 
     def forward(self, x):
-        return torch.cat([
-            self.b0b(self.b0a(x)),
-            self.b1d(self.b1c(self.b1b(self.b1a(x)))),
-            F.max_pool(x, (3, 3), (2, 2), "VALID"),
-        ], dim=3)
+        return _concat(self, x, _reduced(x), [
+            (320, lambda o: self.b0b(self.b0a(x), out=o)),
+            (192, lambda o: self.b1d(self.b1c(self.b1b(self.b1a(x))), out=o)),
+            (x.shape[3], lambda o: F.max_pool(x, (3, 3), (2, 2), "VALID")),
+        ])
 
 
 class _Mixed7(nn.Module):
@@ -137,12 +162,14 @@ class _Mixed7(nn.Module):
     def forward(self, x):
         b1 = self.b1a(x)
         b2 = self.b2b(self.b2a(x))
-        return torch.cat([
-            self.b0(x),
-            self.b1b(b1), self.b1c(b1),
-            self.b2c(b2), self.b2d(b2),
-            self.b3(F.avg_pool(x, (3, 3), (1, 1), "SAME")),
-        ], dim=3)
+        return _concat(self, x, x.shape[1:3], [
+            (320, lambda o: self.b0(x, out=o)),
+            (384, lambda o: self.b1b(b1, out=o)),
+            (384, lambda o: self.b1c(b1, out=o)),
+            (384, lambda o: self.b2c(b2, out=o)),
+            (384, lambda o: self.b2d(b2, out=o)),
+            (192, lambda o: self.b3(F.avg_pool(x, (3, 3), (1, 1), "SAME"), out=o)),
+        ])
 
 
 class _AuxLogitsVars(nn.Module):

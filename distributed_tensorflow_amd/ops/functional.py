@@ -51,6 +51,16 @@ def _use_hip(t: torch.Tensor) -> bool:
     return t.is_cuda and not _force_reference[0]
 
 
+def _needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def concat_plan(x: torch.Tensor, *tensors) -> bool:
+    """True when branch outputs computed from ``x`` may be written straight into channel slices of one
+    buffer: device path and no autograd graph to build (frozen trunk or ``no_grad``)."""
+    return _use_hip(x) and not _needs_grad(x, *tensors)
+
+
 # ----------------------------------------------------------------------------
 # gradient delivery
 # ----------------------------------------------------------------------------
@@ -181,11 +191,25 @@ class _ConvBnActFn(Function):
 
 
 def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, eps, momentum, relu, training,
-                residual=None, residual_grad_slot=None, input_grad_slot=None):
-    """``act(bn(conv(x, weight)) + residual)``; batch statistics when ``training``."""
+                residual=None, residual_grad_slot=None, input_grad_slot=None, out=None):
+    """``act(bn(conv(x, weight)) + residual)``; batch statistics when ``training``.
+
+    ``out`` (device path, nothing requiring grad) is a channel slice of a wider NHWC tensor that
+    receives the result directly -- the way parallel branches are concatenated without a copy."""
     kh, kw = weight.shape[1], weight.shape[2]
     sy, sx = stride
     pads = cv.resolve_pads(padding, x.shape[1], x.shape[2], kh, kw, sy, sx)
+    if out is not None:
+        if not _use_hip(x) or _needs_grad(x, weight, gamma, beta, residual):
+            raise ValueError("out= is a forward-only device path")
+        plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], weight.shape[0], kh, kw, sy, sx, pads, x.device)
+        y, part = cv.conv_fwd(x, weight, plan, want_stats=training)
+        if training:
+            _, _, scale, shift = K.bn_finalize(part, y.numel() // plan.cout, eps, gamma, beta, run_mean, run_var,
+                                               momentum)
+        else:
+            scale, shift = K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
+        return K.bn_apply(y, scale, shift, relu, residual, out=out)
     if not _use_hip(x):
         y = ref.conv2d(x, weight, (sy, sx), pads)
         if training:

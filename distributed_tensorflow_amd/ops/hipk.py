@@ -80,7 +80,7 @@ class _Sigs:
     dtfa_bn_finalize = [c_void, c_int, c_int, c_float, c_float, c_void, c_void, c_void, c_void, c_void, c_void,
                         c_void, c_void, c_float, c_void]
     dtfa_bn_eval_coeffs = [c_int, c_float, c_void, c_void, c_void, c_void, c_void, c_void, c_void]
-    dtfa_bn_apply = [c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_void]
+    dtfa_bn_apply = [c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_int, c_void]
     dtfa_col_partials_rows = [c_ll, c_int]
     dtfa_bn_stats_partials = [c_void, c_void, c_ll, c_int, c_void]
     dtfa_bn_bwd_partials = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_void]
@@ -103,7 +103,7 @@ class _Sigs:
     dtfa_momentum = [c_void, c_void, c_void, c_int, c_void, c_ll, c_void, c_float, c_float, c_int, c_void]
     dtfa_cast_f32_bf16 = [c_void, c_void, c_ll, c_void]
     dtfa_weight_permute = [c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_void]
-    dtfa_dropout = [c_void, c_void, c_ll, C.c_ulonglong, c_float, c_void]
+    dtfa_dropout = [c_void, c_void, c_ll, C.c_ulonglong, c_void, c_float, c_void]
 
 
 def stream() -> int:

@@ -23,10 +23,11 @@ def _as2d(t: torch.Tensor) -> Tuple[int, int]:
 
 
 # ------------------------------------------------------------------ batch norm
-def reduce_partials(part: torch.Tensor, max_rows: int = 64) -> torch.Tensor:
-    """[R][NV][C] -> [RS<=max_rows][NV][C] (fixed summation order)."""
+def reduce_partials(part: torch.Tensor, max_rows: int = 64, direct_rows: int = 2048) -> torch.Tensor:
+    """[R][NV][C] -> [RS<=max_rows][NV][C] (fixed summation order).  Up to ``direct_rows`` rows are left
+    alone: the finalize kernels sum that many themselves (32 row lanes), which saves a launch per layer."""
     R, NV, Cc = part.shape
-    if R <= max_rows:
+    if R <= direct_rows:
         return part
     out = torch.empty((max_rows, NV, Cc), dtype=F32, device=part.device)
     hipk.check(hipk.lib().dtfa_partial_reduce(part.data_ptr(), out.data_ptr(), R, NV, Cc, max_rows, hipk.stream()),
@@ -73,8 +74,23 @@ def bn_eval_coeffs(gamma, beta, run_mean, run_var, eps: float):
     return out[0], out[1]
 
 
+def channel_slice_pitch(out: torch.Tensor, like: torch.Tensor) -> int:
+    """Validate that ``out`` is a channel slice ``buf[..., a:b]`` of a contiguous NHWC buffer with the
+    shape of ``like``; returns its row pitch in elements."""
+    if out.dtype != like.dtype or out.shape != like.shape or out.device != like.device:
+        raise ValueError("output slice does not match the result (shape %s vs %s)" % (tuple(out.shape), tuple(like.shape)))
+    pitch = out.stride(-2)
+    want = [pitch]
+    for d in range(out.dim() - 2, 0, -1):
+        want.insert(0, want[0] * out.shape[d])
+    if out.stride(-1) != 1 or list(out.stride()[:-1]) != want or pitch % 8 or out.data_ptr() % 16:
+        raise ValueError("output must be a 16-byte aligned channel slice of a contiguous NHWC tensor")
+    return pitch
+
+
 def bn_apply(y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool,
-             residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+             residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(y*scale + shift (+ residual))``; ``out`` may be a channel slice of a wider NHWC tensor."""
     hipk.require(y, BF16, "y")
     M, Cc = _as2d(y)
     if scale.numel() != Cc or shift.numel() != Cc:
@@ -83,9 +99,12 @@ def bn_apply(y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bo
         hipk.require(residual, BF16, "residual")
         if residual.shape != y.shape:
             raise ValueError("residual shape mismatch")
-    z = torch.empty_like(y)
+    if out is None:
+        z, ldz = torch.empty_like(y), Cc
+    else:
+        z, ldz = out, channel_slice_pitch(out, y)
     hipk.check(hipk.lib().dtfa_bn_apply(y.data_ptr(), hipk.ptr(residual), z.data_ptr(), scale.data_ptr(),
-                                        shift.data_ptr(), M, Cc, 1 if relu else 0, hipk.stream()), "bn_apply")
+                                        shift.data_ptr(), M, Cc, ldz, 1 if relu else 0, hipk.stream()), "bn_apply")
     return z
 
 
@@ -276,11 +295,26 @@ def mean_f32(v: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ dropout
+_rng_steps = {}
+
+
+def rng_step(device) -> torch.Tensor:
+    """Device-resident step counter folded into every dropout seed (int64[1]).  Advancing it between
+    replays of a captured step graph gives each replay fresh masks."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _rng_steps.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64, device=device)
+        _rng_steps[key] = t
+    return t
+
+
 def dropout(x: torch.Tensor, rate: float, seed: int) -> torch.Tensor:
     hipk.require(x, BF16, "x")
     y = torch.empty_like(x)
-    hipk.check(hipk.lib().dtfa_dropout(x.data_ptr(), y.data_ptr(), x.numel(), seed & ((1 << 64) - 1), float(rate),
-                                       hipk.stream()), "dropout")
+    hipk.check(hipk.lib().dtfa_dropout(x.data_ptr(), y.data_ptr(), x.numel(), seed & ((1 << 64) - 1),
+                                       rng_step(x.device).data_ptr(), float(rate), hipk.stream()), "dropout")
     return y
 
 

@@ -73,13 +73,36 @@ class _RegionOptimizer:
     def current_lr(self) -> float:
         return self.schedule(self.step_count)
 
-    def _hyper_for(self, r: OptRegion, a: float, b: float) -> torch.Tensor:
+    def _hyper_for(self, r: OptRegion) -> torch.Tensor:
         h = self._hyper.get(r.name)
         if h is None:
             h = torch.zeros(2, dtype=torch.float32, device=r.w.device)
             self._hyper[r.name] = h
-        h.copy_(torch.tensor([a, b], dtype=torch.float32), non_blocking=True)
         return h
+
+    # A step is split in a host part and a device part so that the device part can be recorded in a
+    # HIP graph: ``prepare`` evaluates the schedule and uploads (step size, gradient scale) into a
+    # small device array, ``launch`` enqueues kernels that read it, ``advance`` counts the step.
+    def _step_size(self) -> float:
+        raise NotImplementedError
+
+    def prepare(self, grad_scale: float = 1.0) -> None:
+        a = self._step_size()
+        self._host_hyper = (a, float(grad_scale))
+        for r in self.regions:
+            if r.w.is_cuda and r.w.numel():
+                self._hyper_for(r).copy_(torch.tensor([a, grad_scale], dtype=torch.float32), non_blocking=True)
+
+    def launch(self) -> None:
+        raise NotImplementedError
+
+    def advance(self) -> None:
+        self.step_count += 1
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        self.prepare(grad_scale)
+        self.launch()
+        self.advance()
 
     def slots(self) -> Dict[str, torch.Tensor]:
         raise NotImplementedError
@@ -101,10 +124,13 @@ class FusedAdam(_RegionOptimizer):
     def beta2_power(self) -> float:
         return self.b2 ** (self.step_count + 1)
 
-    def step(self, grad_scale: float = 1.0) -> None:
+    def _step_size(self) -> float:
         t = self.step_count + 1
         lr = self.schedule(self.step_count)
-        lr_t = lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+        return lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+
+    def launch(self) -> None:
+        lr_t, grad_scale = self._host_hyper
         for r in self.regions:
             if r.w.numel() == 0:
                 continue
@@ -112,7 +138,7 @@ class FusedAdam(_RegionOptimizer):
             if r.w.is_cuda:
                 from ..ops import kernels as K
 
-                K.adam_step(r.w, m, v, r.g, r.w16, self._hyper_for(r, lr_t, grad_scale), self.b1, self.b2, self.eps)
+                K.adam_step(r.w, m, v, r.g, r.w16, self._hyper_for(r), self.b1, self.b2, self.eps)
             else:
                 gf = r.g.float() * grad_scale
                 m.mul_(self.b1).add_(gf, alpha=1 - self.b1)
@@ -120,7 +146,6 @@ class FusedAdam(_RegionOptimizer):
                 r.w.sub_(lr_t * m / (v.sqrt() + self.eps))
                 if r.w16 is not None:
                     r.w16.copy_(r.w.to(r.w16.dtype))
-        self.step_count += 1
 
     def slots(self):
         out = {}
@@ -136,8 +161,11 @@ class FusedMomentum(_RegionOptimizer):
         self.mu, self.wd, self.nesterov = momentum, weight_decay, nesterov
         self.buf = {r.name: torch.zeros_like(r.w) for r in regions}
 
-    def step(self, grad_scale: float = 1.0) -> None:
-        lr = self.schedule(self.step_count)
+    def _step_size(self) -> float:
+        return self.schedule(self.step_count)
+
+    def launch(self) -> None:
+        lr, grad_scale = self._host_hyper
         for r in self.regions:
             if r.w.numel() == 0:
                 continue
@@ -146,7 +174,7 @@ class FusedMomentum(_RegionOptimizer):
                 from ..ops import kernels as K
 
                 wd = self.wd if r.decay is True else 0.0
-                K.momentum_step(r.w, buf, r.g, r.w16, self._hyper_for(r, lr, grad_scale), self.mu, wd, self.nesterov)
+                K.momentum_step(r.w, buf, r.g, r.w16, self._hyper_for(r), self.mu, wd, self.nesterov)
             else:
                 gp = r.g.float() * grad_scale
                 if self.wd:
@@ -158,7 +186,6 @@ class FusedMomentum(_RegionOptimizer):
                 r.w.sub_(lr * (gp + self.mu * buf if self.nesterov else buf))
                 if r.w16 is not None:
                     r.w16.copy_(r.w.to(r.w16.dtype))
-        self.step_count += 1
 
     def slots(self):
         return {"Momentum/" + r.name: self.buf[r.name] for r in self.regions}

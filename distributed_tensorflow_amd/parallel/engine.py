@@ -155,9 +155,35 @@ class DataParallelEngine:
             self._ring_handles[slot].append(dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.pg,
                                                             async_op=True))
 
-    def finish_step(self) -> None:
+    @property
+    def graph_capturable(self) -> bool:
+        """Every step enqueues the same device work (no step-dependent buffer rotation)."""
+        return not (self.mode == "async_ssp" and self.staleness > 0)
+
+    def prepare_step(self) -> None:
+        """Host part of the optimizer step (schedule -> device hyper-parameters).  ``finish_step``
+        does this itself unless told that it was done, which is how a captured step graph keeps the
+        upload outside the graph."""
+        self.optimizer.prepare(1.0 / self.world)
+
+    def advance_step(self) -> None:
+        """Book-keeping after a replayed step graph (the graph holds only device work)."""
+        self.optimizer.advance()
+        self._step += 1
+
+    def _opt_step(self, scale: float, prepared: bool) -> None:
+        if not prepared:
+            self.optimizer.prepare(scale)
+        self.optimizer.launch()
+        if not prepared:
+            self.optimizer.advance()
+
+    def finish_step(self, prepared: bool = False) -> None:
         """Call after ``loss.backward()``: completes gradient communication,
-        applies the optimizer and (sharded mode) re-assembles parameters."""
+        applies the optimizer and (sharded mode) re-assembles parameters.  With ``prepared`` the
+        caller has run :meth:`prepare_step` and will run :meth:`advance_step` (graph capture)."""
+        if prepared and not self.graph_capturable:
+            raise ValueError("async_ssp with staleness > 0 rotates buffers per step and cannot be captured")
         self.flat.collect_autograd_grads()
         scale = 1.0 / self.world
         if self.mode == "sharded_ps":
@@ -166,7 +192,7 @@ class DataParallelEngine:
                     self._grad_shard[g.name].copy_(g.grad)
             for h in self._handles:
                 h.wait()
-            self.optimizer.step(grad_scale=scale)
+            self._opt_step(scale, prepared)
             self._gather_params()
         elif self.mode == "async_ssp" and self.staleness > 0:
             s = self.staleness
@@ -185,9 +211,10 @@ class DataParallelEngine:
         else:
             for h in self._handles:
                 h.wait()
-            self.optimizer.step(grad_scale=scale)
+            self._opt_step(scale, prepared)
         self._handles = []
-        self._step += 1
+        if not prepared:
+            self._step += 1
 
     def drain(self) -> None:
         """Apply every gradient still in flight (async mode), e.g. before a checkpoint."""

@@ -128,11 +128,16 @@ class SummarySaverHook(Hook):
     chief_only = True
 
     def __init__(self, save_steps: int, output_dir: str, histogram: bool = True):
+        self.save_steps = max(1, save_steps)
+        self.output_dir = output_dir
+        self.writer = None  # opened in begin(): hooks dropped on non-chief ranks never create a file
+        self.histogram = histogram
+
+    def begin(self, session):
         from ..io.events import EventWriter
 
-        self.save_steps = max(1, save_steps)
-        self.writer = EventWriter(output_dir)
-        self.histogram = histogram
+        if self.writer is None:
+            self.writer = EventWriter(self.output_dir)
 
     def after_step(self, session, r):
         if r.global_step % self.save_steps:
@@ -146,7 +151,9 @@ class SummarySaverHook(Hook):
         self.writer.flush()
 
     def end(self, session):
-        self.writer.close()
+        if self.writer is not None:
+            self.writer.close()
+            self.writer = None
 
 
 class TrainingSession:
@@ -161,7 +168,7 @@ class TrainingSession:
 
     def __init__(self, model, engine, *, num_classes: int, hooks: Optional[List[Hook]] = None, is_chief: bool = True,
                  reg_weight: float = 1.0, logits_act_l2: float = 0.0, global_step: int = 0,
-                 keep_logits: bool = False):
+                 keep_logits: bool = False, hip_graph: bool = False, graph_warmup_steps: int = 2):
         self.model, self.engine = model, engine
         self.num_classes = num_classes
         self.is_chief = is_chief
@@ -173,6 +180,12 @@ class TrainingSession:
         self.keep_logits = keep_logits or any(isinstance(h, SummarySaverHook) for h in self.hooks)
         self._stop = False
         self._begun = False
+        # whole-step HIP graph: the first ``graph_warmup_steps`` steps run eagerly (they create
+        # plans, workspaces and collective communicators), then one step is captured and replayed
+        self.hip_graph = bool(hip_graph) and getattr(engine, "graph_capturable", False)
+        self.graph_warmup_steps = max(1, int(graph_warmup_steps))
+        self._graph = None
+        self._eager_steps = 0
 
     # ------------------------------------------------------------------ control
     def request_stop(self) -> None:
@@ -217,15 +230,34 @@ class TrainingSession:
         total = xent if reg is None or not self.reg_weight else xent + self.reg_weight * reg
         return total, xent, logits, top1, score, correct
 
+    def _graph_step(self, images, labels):
+        from .graph import StepGraph
+
+        if self._graph is not None and not self._graph.compatible(images, labels):
+            return None  # odd-sized batch (end of an epoch): run it eagerly
+        if self._graph is None:
+            if self._eager_steps < self.graph_warmup_steps:
+                return None
+            self._graph = StepGraph(self.engine, self.compute_loss, images, labels)
+        return self._graph.run(images, labels)
+
     def run_step(self, images, labels) -> StepResult:
         self._begin()
         t0 = time.perf_counter()
         self.model.train()
-        self.engine.begin_step()
         lr = self.engine.optimizer.current_lr()
-        total, xent, logits, top1, score, correct = self.compute_loss(images, labels)
-        total.backward()
-        self.engine.finish_step()
+        out = self._graph_step(images, labels) if (self.hip_graph and images.is_cuda) else None
+        if out is None:
+            if images.is_cuda:
+                from ..ops import kernels as K
+
+                K.rng_step(images.device).add_(1)
+            self.engine.begin_step()
+            out = self.compute_loss(images, labels)
+            out[0].backward()
+            self.engine.finish_step()
+            self._eager_steps += 1
+        total, xent, logits, top1, score, correct = out
         self.global_step += 1
         # .item() synchronises with the device, so step_time covers the whole step
         loss_v = float(total.detach().float().item())
