@@ -61,6 +61,7 @@ flags.DEFINE_boolean("wipe_checkpoint_dir", False, "ps task 0 deletes checkpoint
 flags.DEFINE_boolean("synthetic", False, "Use synthetic input instead of the TFRecord file.")
 flags.DEFINE_boolean("legacy_bgr_input", False, "Feed BGR [0,255] pixels like the reference's reader.")
 flags.DEFINE_string("device", "auto", "cuda | cpu | auto")
+flags.DEFINE_boolean("hip_graph", False, "collective modes on GPU: replay the step (including its collectives) from a HIP graph")
 flags.DEFINE_string("fault_inject", "", "Testing hook: 'exit_at_step:N' makes this worker die abruptly at global step N.")
 flags.DEFINE_boolean("shutdown_ps", True, "The chief stops the ps tasks when it finishes (the reference's ps never exits).")
 flags.DEFINE_float("worker_timeout", 30.0, "Seconds of silence after which a worker no longer counts for the staleness bound.")
@@ -183,7 +184,8 @@ def run_worker(spec):
     head_l2 = getattr(getattr(model, "head", None), "act_l2", 0.0)
     # the reference scales the activity regulariser by 0.01 in this script (train_dataset.py:159-160)
     sess = TrainingSession(model, engine, num_classes=n_classes, hooks=hooks, is_chief=is_chief, reg_weight=0.01,
-                           logits_act_l2=0.01 * head_l2, global_step=start_step)
+                           logits_act_l2=0.01 * head_l2, global_step=start_step,
+                           hip_graph=FLAGS.hip_graph and device.type == "cuda")
     data = train_input_fn(FLAGS.tfrecords_path, params, device, task_index, world)
     fault_step = int(FLAGS.fault_inject.split(":")[1]) if FLAGS.fault_inject.startswith("exit_at_step:") else None
     t0 = time.time()

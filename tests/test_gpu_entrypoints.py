@@ -1,0 +1,82 @@
+"""The reference entry points on an MI355X: device JPEG decode + resize, HIP kernels, step graph,
+checkpoint, export and serving on the GPU."""
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from distributed_tensorflow_amd.io import bundle
+from distributed_tensorflow_amd.io.export import Servable, example_from_jpeg
+from test_data import _make_dataset
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SINGLE = os.path.join(ROOT, "recognition_flower", "single")
+DIST = os.path.join(ROOT, "recognition_flower", "distributed")
+
+
+def _run(cmd, cwd, timeout=300):
+    e = dict(os.environ)
+    e.pop("TF_CONFIG", None)
+    return subprocess.run([sys.executable] + cmd, cwd=cwd, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                          text=True, timeout=timeout)
+
+
+def test_single_trainer_inception_head_on_gpu(tmp_path):
+    """The reference's own configuration: Inception-v3 trunk (frozen) + flower head, Adam, exponential
+    decay, 299x299 -- trained from JPEG files, exported, and served from the GPU."""
+    data = _make_dataset(str(tmp_path / "flowers"), n_per_class=12)
+    out = tmp_path / "out"
+    r = _run(["flower_train.py", "--dataset_path=" + data, "--n_epochs=6", "--batch_size=8", "--device=cuda",
+              "--output_dir=%s/models" % out, "--summaries_dir=%s/events/" % out, "--checkpoint_dir=%s/ckpt" % out], SINGLE)
+    assert r.returncode == 0, r.stdout[-3000:]
+    losses = [float(m) for m in re.findall(r"loss (\d+\.\d+)", r.stdout)]
+    assert len(losses) >= 12 and all(np.isfinite(losses))
+    assert np.mean(losses[-4:]) < np.mean(losses[:4])
+    keys = {e[0] for e in bundle.list_bundle(bundle.latest_checkpoint(str(out / "ckpt")))}
+    assert {"InceptionV3/Conv2d_1a_3x3/weights", "InceptionV3/Mixed_7c/Branch_1/Conv2d_0c_3x1/BatchNorm/beta",
+            "InceptionV3/AuxLogits/Conv2d_2b_1x1/biases", "InceptionV3/Logits/Conv2d_1c_1x1/weights",
+            "fc_trainable/dense_prelogit1/kernel", "fc_trainable/flower_logits/kernel/Adam", "global_step"} <= keys
+    export = out / "models" / "1"
+    s = Servable(str(export), device="cuda")
+    jpegs = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(data, "*", "*.jpg")))[:5]]
+    a = s.predict_images(jpegs)
+    b = s.serving_default([example_from_jpeg(j) for j in jpegs])
+    assert a["classes"].shape == (5, 1) and a["scores"].dtype == np.float32
+    assert a["classes"].tolist() == b["classes"].tolist() and np.allclose(a["scores"], b["scores"])
+    # the same servable on the CPU reference path agrees on the scores up to bf16 noise
+    c = Servable(str(export), device="cpu").predict_images(jpegs)
+    assert np.abs(c["scores"] - a["scores"]).max() < 0.15 * max(1.0, np.abs(c["scores"]).max())
+
+
+def test_collective_trainer_checkpoint_resume_export_on_gpu(tmp_path):
+    data = _make_dataset(str(tmp_path / "flowers"), n_per_class=8)
+    rec = str(tmp_path / "train.tfrecord")
+    r = _run(["prepare.py", "--dataset_path=" + data, "--tfrecords_path=" + rec, "--seed=3"], DIST)
+    assert r.returncode == 0, r.stdout
+    common = ["train_dataset.py", "--tfrecords_path=" + rec, "--checkpoint_dir=%s/ckpt/" % tmp_path,
+              "--summaries_dir=%s/events/" % tmp_path, "--batch_size=8", "--image_size=64", "--model=flower_cnn",
+              "--device=cuda", "--learning_rate=0.003"]
+    r1 = _run(common + ["--mode=sharded_ps", "--train_steps=12", "--hip_graph=true"], DIST)
+    assert r1.returncode == 0, r1.stdout[-3000:]
+    latest, _ = bundle.read_checkpoint_state(str(tmp_path / "ckpt"))
+    assert latest == "model.ckpt-12"
+    # resume in a different mode from the same files; the global step continues
+    r2 = _run(common + ["--mode=sync_dp", "--train_steps=18", "--resume=true"], DIST)
+    assert r2.returncode == 0 and "resumed from global step 12" in r2.stdout, r2.stdout[-3000:]
+    assert bundle.read_checkpoint_state(str(tmp_path / "ckpt"))[0] == "model.ckpt-18"
+    r3 = _run(["save_model.py", "--checkpoint_dir=%s/ckpt/" % tmp_path, "--output_dir=%s/models" % tmp_path,
+               "--dataset_path=" + data, "--model=flower_cnn", "--image_size=64", "--device=cuda"], DIST)
+    assert r3.returncode == 0 and "Done exporting!" in r3.stdout, r3.stdout[-3000:]
+    manifest = json.load(open(tmp_path / "models" / "1" / "saved_model.json"))
+    assert manifest["classes"] == ["daisy", "roses", "tulips"] and manifest["global_step"] == 18
+    s = Servable(str(tmp_path / "models" / "1"), device="cuda")
+    jpegs = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(data, "*", "*.jpg")))[:3]]
+    out = s.predict_images(jpegs)
+    assert out["classes"].shape == (3, 1) and np.isfinite(out["scores"]).all()
