@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default depends on the model)")
     ap.add_argument("--bucket_mb", type=float, default=32.0)
     ap.add_argument("--staleness", type=int, default=1)
+    ap.add_argument("--p2p_kb", type=int, default=0,
+                    help="gradient buckets up to this many KiB use the one-shot xGMI mailbox all-reduce (sync_dp)")
     ap.add_argument("--hip_graph", type=int, default=0,
                     help="1: record the whole step (fwd, bwd, collectives, optimizer) in a HIP graph and replay it")
     args = ap.parse_args()
@@ -73,7 +75,7 @@ def main():
         # a fixed synthetic batch with random labels: a small constant rate keeps the loss finite at any world size
         opt, lr, okw = "momentum", 0.02, {"momentum": 0.9, "weight_decay": 1e-4}
     engine = DataParallelEngine(model, mode=args.mode, optimizer=opt, lr=lr, opt_kwargs=okw,
-                                bucket_mb=args.bucket_mb, staleness=args.staleness)
+                                bucket_mb=args.bucket_mb, staleness=args.staleness, p2p_max_bytes=args.p2p_kb * 1024)
 
     g = torch.Generator(device="cpu").manual_seed(rank)
     images = torch.zeros(batch, size, size, 8)

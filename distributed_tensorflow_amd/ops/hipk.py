@@ -104,6 +104,11 @@ class _Sigs:
     dtfa_cast_f32_bf16 = [c_void, c_void, c_ll, c_void]
     dtfa_weight_permute = [c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_void]
     dtfa_dropout = [c_void, c_void, c_ll, C.c_ulonglong, c_void, c_float, c_void]
+    dtfa_p2p_create = [c_int, c_int, c_ll, C.c_double, C.POINTER(c_void)]
+    dtfa_p2p_handle = [c_void, C.c_char_p]
+    dtfa_p2p_connect = [c_void, C.c_char_p]
+    dtfa_p2p_allreduce = [c_void, c_void, c_void, c_ll, c_int, c_float, c_void]
+    dtfa_p2p_status = [c_void]
 
 
 def stream() -> int:

@@ -53,7 +53,7 @@ MODES = ("sync_dp", "sharded_ps", "async_ssp")
 class DataParallelEngine:
     def __init__(self, model: nn.Module, *, mode: str = "sync_dp", optimizer: str = "momentum", lr=0.1,
                  opt_kwargs: Optional[dict] = None, bucket_mb: float = 32.0, staleness: int = 1,
-                 process_group=None, grad_dtype: torch.dtype = torch.float32):
+                 process_group=None, grad_dtype: torch.dtype = torch.float32, p2p_max_bytes: int = 0):
         if mode not in MODES:
             raise ValueError("mode must be one of %s" % (MODES,))
         self.model = model
@@ -81,6 +81,13 @@ class DataParallelEngine:
                 {g.name: torch.zeros_like(g.grad) for g in self.flat.groups} for _ in range(self.staleness + 1)
             ]
             self._ring_handles: List[List] = [[] for _ in range(self.staleness + 1)]
+        # buckets up to ``p2p_max_bytes`` skip RCCL and use the one-shot xGMI mailbox all-reduce
+        self._p2p = None
+        if p2p_max_bytes > 0 and self.distributed and self.world > 1 and mode == "sync_dp" \
+                and self.flat.groups[0].grad.is_cuda:
+            from .p2p import P2PAllReduce
+
+            self._p2p = P2PAllReduce(p2p_max_bytes, group=self.pg)
         if self.distributed and self.world > 1:
             self.broadcast_parameters()
 
@@ -141,7 +148,10 @@ class DataParallelEngine:
         g = b.group
         grad = g.grad[b.start:b.end]
         if self.mode == "sync_dp" or (self.mode == "async_ssp" and self.staleness == 0):
-            self._handles.append(dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            if self._p2p is not None and self._p2p.fits(grad):
+                self._p2p.all_reduce_(grad)  # in stream order, nothing to wait for on the host
+            else:
+                self._handles.append(dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         elif self.mode == "sharded_ps":
             p = b.numel // self.world
             off = b.start // self.world
@@ -158,7 +168,8 @@ class DataParallelEngine:
     @property
     def graph_capturable(self) -> bool:
         """Every step enqueues the same device work (no step-dependent buffer rotation)."""
-        return not (self.mode == "async_ssp" and self.staleness > 0)
+        # (the mailbox all-reduce passes its sequence number as a kernel argument)
+        return not (self.mode == "async_ssp" and self.staleness > 0) and self._p2p is None
 
     def prepare_step(self) -> None:
         """Host part of the optimizer step (schedule -> device hyper-parameters).  ``finish_step``

@@ -61,6 +61,7 @@ flags.DEFINE_boolean("wipe_checkpoint_dir", False, "ps task 0 deletes checkpoint
 flags.DEFINE_boolean("synthetic", False, "Use synthetic input instead of the TFRecord file.")
 flags.DEFINE_boolean("legacy_bgr_input", False, "Feed BGR [0,255] pixels like the reference's reader.")
 flags.DEFINE_string("device", "auto", "cuda | cpu | auto")
+flags.DEFINE_integer("p2p_small_kb", 0, "sync_dp on GPUs: gradient buckets up to this size use the one-shot xGMI mailbox all-reduce instead of RCCL (0 = off)")
 flags.DEFINE_boolean("hip_graph", False, "collective modes on GPU: replay the step (including its collectives) from a HIP graph")
 flags.DEFINE_string("fault_inject", "", "Testing hook: 'exit_at_step:N' makes this worker die abruptly at global step N.")
 flags.DEFINE_boolean("shutdown_ps", True, "The chief stops the ps tasks when it finishes (the reference's ps never exits).")
@@ -165,7 +166,8 @@ def run_worker(spec):
             dist.init_process_group("nccl" if device.type == "cuda" else "gloo", rank=task_index, world_size=world)
         mode = "sync_dp" if FLAGS.mode == "async_ps" else FLAGS.mode
         engine = DataParallelEngine(model, mode=mode, optimizer="adam", lr=params["learning_rate"],
-                                    bucket_mb=FLAGS.bucket_mb, staleness=max(FLAGS.staleness, 0))
+                                    bucket_mb=FLAGS.bucket_mb, staleness=max(FLAGS.staleness, 0),
+                                    p2p_max_bytes=FLAGS.p2p_small_kb * 1024)
     saver = Saver(model, engine)
     start_step = 0
     # async_ps: the chief restores and uploads to the ps tasks; collective modes: every rank loads the file

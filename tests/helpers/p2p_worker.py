@@ -1,0 +1,57 @@
+"""Rank process of tests/test_gpu_p2p.py: two ranks share one GPU; handles travel over gloo."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from distributed_tensorflow_amd.parallel.p2p import P2PAllReduce  # noqa: E402
+
+
+def data(rank, n, dtype, it):
+    g = torch.Generator().manual_seed(1000 * it + rank)
+    return torch.randn(n, generator=g).to(dtype)
+
+
+def main():
+    rank, world, port, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    p2p = P2PAllReduce(max_bytes=1 << 20, timeout_s=2.0 if mode == "timeout" else 20.0)
+    if mode == "timeout":
+        if rank == 0:
+            t = torch.ones(1024, device="cuda")
+            p2p.all_reduce_(t)
+            try:
+                p2p.check()
+            except RuntimeError as e:
+                print("TIMEOUT_DETECTED", e, flush=True)
+        dist.barrier()
+        os._exit(0)
+    it = 0
+    for dtype in (torch.float32, torch.bfloat16):
+        for n in (8, 1024, 4096 + 8, 65536, (1 << 20) // 4 if dtype == torch.float32 else (1 << 20) // 2):
+            for rep in range(5):
+                it += 1
+                mine = data(rank, n, dtype, it).cuda()
+                want = sum(data(r, n, dtype, it).float() for r in range(world)) * 0.5
+                p2p.all_reduce_(mine, scale=0.5)
+                got = mine.float().cpu()
+                tol = 0 if dtype == torch.float32 else 2e-2
+                err = (got - want).abs().max().item()
+                assert err <= tol * max(1.0, want.abs().max().item()), (dtype, n, rep, err)
+    p2p.check()
+    # results are bit-identical across ranks
+    t = data(rank, 4096, torch.float32, 999).cuda()
+    p2p.all_reduce_(t)
+    both = [None, None]
+    dist.all_gather_object(both, t.cpu())
+    assert torch.equal(both[0], both[1])
+    p2p.close()
+    print("P2P_OK rank", rank, "calls", it, flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,45 @@
+"""One-shot mailbox all-reduce: two rank processes on one GPU (IPC-mapped mailboxes, flag protocol,
+double buffering, rank-ordered summation, timeout when a peer never arrives)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "p2p_worker.py")
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
+def _launch(mode):
+    port = _port()
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), "2", port, mode], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=150)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return procs, outs
+
+
+def test_p2p_allreduce_two_ranks_one_gpu():
+    procs, outs = _launch("run")
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "P2P_OK" in o, o[-3000:]
+
+
+def test_p2p_allreduce_times_out_without_peer():
+    procs, outs = _launch("timeout")
+    assert procs[0].returncode == 0 and "TIMEOUT_DETECTED" in outs[0], outs[0][-3000:]
