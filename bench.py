@@ -60,7 +60,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X GPU")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run, any N
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if world != args.gpus and rank == 0:
@@ -96,7 +97,7 @@ def main():
         return loss
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -125,7 +126,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
     ips = batch * world * args.steps / dt
@@ -149,7 +150,7 @@ def main():
                        "optimizer": opt, "hip_graph": bool(args.hip_graph)},
             "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2**30, 2),
         }), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

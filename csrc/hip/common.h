@@ -27,6 +27,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Wait until at most N vector-memory operations (LDS-DMA loads included) are outstanding.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 __device__ __forceinline__ float bf16_to_f32(bf16 v) { return (float)v; }
 __device__ __forceinline__ bf16 f32_to_bf16(float v) { return (bf16)v; }

@@ -21,8 +21,8 @@
 // im2col gather is expressed in the per-lane *source* address, padding is a
 // read from a zero page, and the LDS image is XOR-swizzled through the source
 // chunk choice so that ds_read_b128 fragment reads are bank-conflict free.
-// Two LDS stages: the loads of k-tile t+1 are in flight while tile t is
-// multiplied.  The epilogue optionally adds a bias, applies ReLU, emits
+// Three LDS stages: while k-tile t is multiplied, tile t+1 is landing and
+// tile t+2 is being requested.  The epilogue optionally adds a bias, applies ReLU, emits
 // per-channel sum / sum-of-squares partials for a following batch-norm, and
 // stores bf16 rows through LDS so that global stores are 16 B per lane.
 #include "common.h"
@@ -59,7 +59,13 @@ __device__ __forceinline__ int swz_of_row(int row) {
 
 // EPI selects the epilogue at compile time: 0 = plain store (data-gradient, no statistics),
 // 1 = batch-norm partial statistics, 2 = bias (+ optional ReLU).
-template <int BM, int BN, int BK, int EPI>
+// Timing-only builds for attributing main-loop time (results are wrong): -DDTFA_DBG=1 drops the global
+// loads of the main loop, =2 replaces the MFMAs by one scalar FMA per fragment pair, =3 both.
+#ifndef DTFA_DBG
+#define DTFA_DBG 0
+#endif
+
+template <int BM, int BN, int BK, int EPI, int NST>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   constexpr int S = BK / 8;            // 16-byte slots per LDS row
   constexpr int ROWB = BK * 2;         // bytes per LDS row
@@ -189,42 +195,74 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
 
   const int KT = (p.K + BK - 1) / BK;
+  constexpr int LPS = NA + NB;  // LDS-DMA loads per thread and stage
+  static_assert(KS % 2 == 0, "fragment double-buffering assumes an even number of k-steps per tile");
+  // NST LDS stages (2 or 3): while k-tile kt is multiplied, the tiles up to kt+NST-1 are in flight.
+  // Within a tile the fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks run, and
+  // the first fragments of tile kt+1 are read behind the barrier, ahead of the last MFMAs of tile kt.
+  static_assert(NST == 2 || NST == 3, "two or three LDS stages");
   stage(0, 0);
-  wait_vmcnt0();
+  if (NST == 3 && KT > 1) {
+    stage(1, 1);
+    wait_vmcnt<LPS>();
+  } else {
+    wait_vmcnt<0>();
+  }
   __syncthreads();
 
-  int cur = 0;
+  bf16x8 af[2][MT], bfr[2][NT];
+  auto read_frags = [&](int buf, int ks, int dst) {
+    const char* base = lds_tiles + buf * STAGE;
+    const int sl = ks * 2 + khalf;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[dst][mt] = *(const bf16x8*)(base + aoff[mt] + ((sl ^ aswz[mt]) << 4));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bfr[dst][nt] = *(const bf16x8*)(base + boff[nt] + ((sl ^ bswz[nt]) << 4));
+  };
+  auto mfma_step = [&](int src) {
+#if (DTFA_DBG & 2)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt][0] += (float)af[src][mt][0] * (float)bfr[src][nt][0];
+#else
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[src][mt], bfr[src][nt], acc[mt][nt], 0, 0, 0);
+#endif
+  };
+
+  read_frags(0, 0, 0);
+  int cur = 0;  // kt % NST
   for (int kt = 0; kt < KT; ++kt) {
-    if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
-    const char* base = lds_tiles + cur * STAGE;
-    // fragments of k-step ks+1 are fetched from LDS while the MFMAs of k-step ks run
-    bf16x8 af[2][MT], bfr[2][NT];
+    const int nxt = cur == NST - 1 ? 0 : cur + 1;
+    // the slot requested here held tile kt-1, which every wave finished reading before the last barrier
+    if (kt + NST - 1 < KT && !(DTFA_DBG & 1)) stage(kt + NST - 1, NST == 2 ? nxt : (nxt == 2 ? 0 : nxt + 1));
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) af[0][mt] = *(const bf16x8*)(base + aoff[mt] + ((khalf ^ aswz[mt]) << 4));
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bfr[0][nt] = *(const bf16x8*)(base + boff[nt] + ((khalf ^ bswz[nt]) << 4));
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int c = ks & 1, n = c ^ 1;
-      if (ks + 1 < KS) {
-        const int sl = (ks + 1) * 2 + khalf;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          af[n][mt] = *(const bf16x8*)(base + aoff[mt] + ((sl ^ aswz[mt]) << 4));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          bfr[n][nt] = *(const bf16x8*)(base + boff[nt] + ((sl ^ bswz[nt]) << 4));
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][mt], bfr[c][nt], acc[mt][nt], 0, 0, 0);
+    for (int ks = 0; ks + 1 < KS; ++ks) {
+      read_frags(cur, ks + 1, (ks + 1) & 1);
+      // keep the reads ahead of the MFMAs: left alone the scheduler sinks them and reuses one register set
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    wait_vmcnt0();
-    __syncthreads();
-    cur ^= 1;
+    if (kt + 1 < KT) {
+      // this wave's reads of tile kt are complete and everything but the stage just requested has landed;
+      // after the barrier tile kt+1 is visible to all waves and tile kt's slot may be overwritten
+      // (a raw barrier: __syncthreads() would add a fence that drains every outstanding LDS-DMA load)
+      if (NST == 3 && kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      read_frags(nxt, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_step((KS - 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
   }
+  __syncthreads();  // all fragment reads done before the tiles are reused by the epilogue
 
   // ---- epilogue: bias / relu / bn partial statistics / bf16 rows via LDS ----
   char* ep = lds_tiles + wid * (WM * EP_PITCH);
@@ -295,40 +333,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   }
 }
 
-template <int BM, int BN, int BK, int EPI>
+template <int BM, int BN, int BK, int EPI, int NST>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   constexpr int ROWB = BK * 2;
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int EP = 4 * (BM / 2) * ((BN / 2) * 2 + 16);
-  size_t lds = MAX_TAPS * 4 + (size_t)((2 * STAGE > EP) ? 2 * STAGE : EP);
+  size_t lds = MAX_TAPS * 4 + (size_t)((NST * STAGE > EP) ? NST * STAGE : EP);
   unsigned mtiles = (a.M + BM - 1) / BM, ntiles = (a.Cout + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, EPI>,
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, EPI, NST>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, EPI>), dim3(mtiles * ntiles), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, EPI, NST>), dim3(mtiles * ntiles), dim3(256), lds, stream, a);
   return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int NST>
 static int launch_conv_epi(const ConvArgs& a, hipStream_t stream) {
-  if (a.stats != nullptr) return launch_conv<BM, BN, BK, 1>(a, stream);
-  if (a.bias != nullptr || a.relu) return launch_conv<BM, BN, BK, 2>(a, stream);
-  return launch_conv<BM, BN, BK, 0>(a, stream);
+  if (a.stats != nullptr) return launch_conv<BM, BN, BK, 1, NST>(a, stream);
+  if (a.bias != nullptr || a.relu) return launch_conv<BM, BN, BK, 2, NST>(a, stream);
+  return launch_conv<BM, BN, BK, 0, NST>(a, stream);
 }
 
 // Number of partial-statistics rows the kernel writes for a given M and BM.
 extern "C" int dtfa_conv_stats_rows(int M, int bm) { return ((M + bm - 1) / bm) * 2; }
 
-extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, hipStream_t stream) {
+extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int nst, hipStream_t stream) {
   if (a->Cin % 8 != 0 || a->Cout % 8 != 0 || a->T > MAX_TAPS || a->T < 1) return -1;
   if (a->K != a->T * a->Cin || a->K >= (1 << 16)) return -2;
   if (a->stats != nullptr && a->bias != nullptr) return -4;
   if (a->M <= 0) return 0;
-#define CASE(BM_, BN_, BK_) \
-  if (bm == BM_ && bn == BN_ && bk == BK_) return launch_conv_epi<BM_, BN_, BK_>(*a, stream);
+#define CASE(BM_, BN_, BK_)                                                                   \
+  if (bm == BM_ && bn == BN_ && bk == BK_) {                                                  \
+    if (nst == 2) return launch_conv_epi<BM_, BN_, BK_, 2>(*a, stream);                       \
+    if (nst == 3) return launch_conv_epi<BM_, BN_, BK_, 3>(*a, stream);                       \
+  }
   CASE(128, 128, 32)
   CASE(128, 64, 32)
   CASE(64, 64, 32)

@@ -272,7 +272,7 @@ static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t stream) {
   unsigned mt = (a.Cout + BMW - 1) / BMW, nt = (a.K + BNW - 1) / BNW;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, BKP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, BKP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   unsigned split_groups = (splits + 7) / 8;

@@ -26,7 +26,8 @@ class NativeLibraryError(RuntimeError):
 
 
 def hip_path() -> str:
-    return os.path.join(_HERE, "libdtfa_hip.so")
+    # DTFA_HIP_LIB points experiments (tools/build_variant.py) at an alternative build of the kernels
+    return os.environ.get("DTFA_HIP_LIB") or os.path.join(_HERE, "libdtfa_hip.so")
 
 
 def host_path() -> str:

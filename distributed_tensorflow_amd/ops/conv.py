@@ -161,21 +161,23 @@ def _env_tile(name: str):
     return tuple(int(t) for t in v.split(","))
 
 
-def pick_fwd_tile(M: int, cout: int, K: int) -> Tuple[int, int, int]:
-    """(BM, BN, BK) of the implicit-GEMM kernel.  Chosen from a sweep over the ResNet-50 layer shapes
+def pick_fwd_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
+    """(BM, BN, BK, LDS stages) of the implicit-GEMM kernel.  Chosen from a sweep over the ResNet-50 layer shapes
     at batch 256 on MI355X (tools/sweep_conv.py): deep reductions (3x3 convs, K >= 576) want BK = 64;
     short ones (1x1 convs, memory-bound) want BK = 32 and the higher occupancy it allows; the 256-row
     tile never won."""
     forced = _env_tile("DTFA_CONV_TILE")
     if forced:
-        return forced  # type: ignore[return-value]
+        return tuple(forced) if len(forced) == 4 else tuple(forced) + (2,)  # type: ignore[return-value]
     bk = 64 if K >= 576 else 32
     bn = 128 if cout > 64 else 64
     bm = 128
     tiles = -(-M // bm) * -(-cout // bn)
     if bn == 64 and tiles < 512:
         bm = 64
-    return bm, bn, bk
+    # deep tiles: two 32 KB stages (two workgroups per CU); shallow ones: three 16 KB stages, which keeps
+    # two k-tiles of loads in flight at three workgroups per CU
+    return bm, bn, bk, (2 if bk == 64 else 3)
 
 
 def pick_wgrad_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
@@ -200,7 +202,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
                   cin_magic, bias=None, relu=False, stats=False, addend=None, zero_taps=False):
     M = B * oyn * oxn
     K = T * cin
-    bm, bn, bk = pick_fwd_tile(M, cout, K)
+    bm, bn, bk, nst = pick_fwd_tile(M, cout, K)
     L = hipk.lib()
     part = None
     if stats:
@@ -225,7 +227,8 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     # 1x1 / stride 1 / no padding: input pixel index == output pixel index, the kernel skips the pixel decode
     a.pointwise = 1 if (zero_taps and a.dense_out and T == 1 and isy == 1 and isx == 1
                         and ih == oyn and iw == oxn) else 0
-    hipk.check(L.dtfa_conv_igemm(C.byref(a), bm, bn, bk, hipk.stream()), "conv_igemm %dx%dx%d" % (bm, bn, bk))
+    hipk.check(L.dtfa_conv_igemm(C.byref(a), bm, bn, bk, nst, hipk.stream()),
+               "conv_igemm %dx%dx%d/%d" % (bm, bn, bk, nst))
     return part
 
 

@@ -72,7 +72,7 @@ def lib():
 
 
 class _Sigs:
-    dtfa_conv_igemm = [C.POINTER(ConvArgs), c_int, c_int, c_int, c_void]
+    dtfa_conv_igemm = [C.POINTER(ConvArgs), c_int, c_int, c_int, c_int, c_void]
     dtfa_conv_stats_rows = [c_int, c_int]
     dtfa_conv_wgrad = [C.POINTER(WgradArgs), c_int, c_int, c_int, c_int, c_void]
     dtfa_wgrad_reduce = [c_void, c_int, c_ll, c_void, c_void, c_int, c_void]

@@ -37,6 +37,7 @@ multi-process tests exercise it.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -62,6 +63,9 @@ class DataParallelEngine:
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(self.pg) if self.distributed else 1
         self.rank = dist.get_rank(self.pg) if self.distributed else 0
+        # collectives are skipped in a world of one, unless DTFA_FORCE_COLLECTIVES=1 asks for them anyway
+        # (a one-rank RCCL run then exercises the same calls as a multi-GPU job)
+        self.collective = self.distributed and (self.world > 1 or os.environ.get("DTFA_FORCE_COLLECTIVES") == "1")
         self.staleness = max(0, int(staleness)) if mode == "async_ssp" else 0
         shard_multiple = self.world if mode == "sharded_ps" else 1
         self.flat = FlatParams(model, bucket_mb=bucket_mb, shard_multiple=shard_multiple, grad_dtype=grad_dtype)
@@ -83,12 +87,12 @@ class DataParallelEngine:
             self._ring_handles: List[List] = [[] for _ in range(self.staleness + 1)]
         # buckets up to ``p2p_max_bytes`` skip RCCL and use the one-shot xGMI mailbox all-reduce
         self._p2p = None
-        if p2p_max_bytes > 0 and self.distributed and self.world > 1 and mode == "sync_dp" \
+        if p2p_max_bytes > 0 and self.collective and mode == "sync_dp" \
                 and self.flat.groups[0].grad.is_cuda:
             from .p2p import P2PAllReduce
 
             self._p2p = P2PAllReduce(p2p_max_bytes, group=self.pg)
-        if self.distributed and self.world > 1:
+        if self.collective:
             self.broadcast_parameters()
 
     # ------------------------------------------------------------------ setup
@@ -143,7 +147,7 @@ class DataParallelEngine:
         self._handles = []
 
     def _on_bucket_ready(self, b: Bucket) -> None:
-        if not self.distributed or self.world == 1:
+        if not self.collective:
             return
         g = b.group
         grad = g.grad[b.start:b.end]
@@ -198,7 +202,7 @@ class DataParallelEngine:
         self.flat.collect_autograd_grads()
         scale = 1.0 / self.world
         if self.mode == "sharded_ps":
-            if self.world == 1 or not self.distributed:
+            if not self.collective:
                 for g in self.flat.groups:
                     self._grad_shard[g.name].copy_(g.grad)
             for h in self._handles:
@@ -208,7 +212,7 @@ class DataParallelEngine:
         elif self.mode == "async_ssp" and self.staleness > 0:
             s = self.staleness
             slot = self._step % (s + 1)
-            if self.world == 1 or not self.distributed:
+            if not self.collective:
                 for g in self.flat.groups:
                     self._ring[slot][g.name].copy_(g.grad)
             if self._step >= s:
@@ -250,7 +254,7 @@ class DataParallelEngine:
             for b, off, p in self._pieces(g):
                 src = src_all[off:off + p]
                 dst = dst_all[b.start:b.end]
-                if self.distributed and self.world > 1:
+                if self.collective:
                     handles.append(dist.all_gather_into_tensor(dst, src, group=self.pg, async_op=True))
                 else:
                     dst.copy_(src)
@@ -269,7 +273,7 @@ class DataParallelEngine:
             ms = self._master_shard[g.name]
             for b, off, p in self._pieces(g):
                 dst = full[b.start:b.end]
-                if self.distributed and self.world > 1:
+                if self.collective:
                     dist.all_gather_into_tensor(dst, ms[off:off + p].contiguous(), group=self.pg)
                 else:
                     dst.copy_(ms[off:off + p])
@@ -290,7 +294,7 @@ class DataParallelEngine:
             full = torch.zeros(g.total, dtype=t.dtype, device=t.device)
             for b, off, p in self._pieces(g):
                 dst = full[b.start:b.end]
-                if self.distributed and self.world > 1:
+                if self.collective:
                     dist.all_gather_into_tensor(dst, t[off:off + p].contiguous(), group=self.pg)
                 else:
                     dst.copy_(t[off:off + p])

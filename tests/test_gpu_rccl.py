@@ -1,0 +1,43 @@
+"""The collective engine on real RCCL.  One rank per process is all a one-GPU box allows, so the job is a
+world of one launched through torch.distributed.run with DTFA_FORCE_COLLECTIVES=1: every bucketed
+all-reduce / reduce-scatter / all-gather, the staleness ring, the mailbox all-reduce and the captured
+step graph issue exactly the calls a multi-GPU job issues."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
+@pytest.mark.parametrize("extra", [
+    ["--mode", "sync_dp"],
+    ["--mode", "sharded_ps"],
+    ["--mode", "async_ssp", "--staleness", "2"],
+    ["--mode", "sync_dp", "--p2p_kb", "4096", "--bucket_mb", "1"],
+    ["--mode", "sync_dp", "--hip_graph", "1"],
+    ["--mode", "sharded_ps", "--hip_graph", "1"],
+])
+def test_bench_under_torchrun_one_rank(extra):
+    env = dict(os.environ, DTFA_FORCE_COLLECTIVES="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", _port(), "bench.py", "--gpus", "1", "--model", "flower_cnn", "--batch", "32",
+           "--steps", "4", "--warmup", "2"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["final_loss"] == out["final_loss"]  # finite
+    assert out["final_loss"] < 5.0

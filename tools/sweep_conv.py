@@ -11,7 +11,7 @@ from tools.bench_conv import RESNET, timeit  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 which = sys.argv[2] if len(sys.argv) > 2 else "fwd"
-FWD = [(128, 128, 32), (128, 128, 64), (128, 64, 32), (128, 64, 64), (64, 64, 32), (64, 64, 64)]
+FWD = [(bm, bn, bk, nst) for (bm, bn) in ((128, 128), (128, 64), (64, 64)) for bk in (32, 64) for nst in (2, 3)]
 WG = [(128, 128, 32), (64, 128, 32), (128, 64, 32), (64, 64, 32), (128, 128, 64), (64, 128, 64)]
 for (H, W, Cin, Cout, k, s, pad) in RESNET:
     plan = cv.get_plan(H, W, Cin, Cout, k, k, s, s, (pad,) * 4, "cuda")
@@ -23,7 +23,7 @@ for (H, W, Cin, Cout, k, s, pad) in RESNET:
         if which == "dgrad" and Cin == 8:
             continue
         for t in FWD:
-            os.environ["DTFA_CONV_TILE"] = "%d,%d,%d" % t
+            os.environ["DTFA_CONV_TILE"] = ",".join(map(str, t))
             fn = (lambda: cv.conv_fwd(x, w, plan, want_stats=True)) if which == "fwd" else (lambda: cv.conv_dgrad(dy, w, plan))
             try:
                 res.append((timeit(fn, 5) * 1e6, t))
