@@ -151,3 +151,15 @@ extern "C" int dtfa_cast_f32_bf16(const float* src, void* dst, long long n, hipS
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(opt_grid(n)), dim3(256), 0, st, src, (bf16*)dst, (size_t)n);
   return (int)hipGetLastError();
 }
+
+// Upload the two per-step optimizer scalars (step size, gradient scale).  Kernel arguments are captured
+// at launch, so the upload is ordered in the stream without any host buffer that has to stay alive.
+__global__ void set_hyper_kernel(float* __restrict__ dst, float a, float b) {
+  if (threadIdx.x == 0) dst[0] = a;
+  if (threadIdx.x == 1) dst[1] = b;
+}
+
+extern "C" int dtfa_set_hyper(float* dst, float a, float b, hipStream_t st) {
+  hipLaunchKernelGGL(set_hyper_kernel, dim3(1), dim3(64), 0, st, dst, a, b);
+  return (int)hipGetLastError();
+}

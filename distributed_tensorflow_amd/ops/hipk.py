@@ -102,6 +102,7 @@ class _Sigs:
     dtfa_adam = [c_void, c_void, c_void, c_void, c_int, c_void, c_ll, c_void, c_float, c_float, c_float, c_void]
     dtfa_momentum = [c_void, c_void, c_void, c_int, c_void, c_ll, c_void, c_float, c_float, c_int, c_void]
     dtfa_cast_f32_bf16 = [c_void, c_void, c_ll, c_void]
+    dtfa_set_hyper = [c_void, c_float, c_float, c_void]
     dtfa_weight_permute = [c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_void]
     dtfa_dropout = [c_void, c_void, c_ll, C.c_ulonglong, c_void, c_float, c_void]
     dtfa_p2p_create = [c_int, c_int, c_ll, C.c_double, C.POINTER(c_void)]

@@ -91,7 +91,10 @@ class _RegionOptimizer:
         self._host_hyper = (a, float(grad_scale))
         for r in self.regions:
             if r.w.is_cuda and r.w.numel():
-                self._hyper_for(r).copy_(torch.tensor([a, grad_scale], dtype=torch.float32), non_blocking=True)
+                from ..ops import hipk
+
+                hipk.check(hipk.lib().dtfa_set_hyper(self._hyper_for(r).data_ptr(), float(a), float(grad_scale),
+                                                     hipk.stream()), "set_hyper")
 
     def launch(self) -> None:
         raise NotImplementedError

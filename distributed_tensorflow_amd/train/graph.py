@@ -47,7 +47,10 @@ class StepGraph:
         eng = self.engine
         torch.cuda.synchronize()
         eng.prepare_step()
-        with torch.cuda.graph(self.graph):
+        # With collectives in the step, RCCL's watchdog thread keeps polling events of earlier work while
+        # the capture runs; "thread_local" keeps those calls from invalidating the capture.
+        mode = "thread_local" if getattr(eng, "collective", False) else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             eng.begin_step()
             out = loss_fn(self.images, self.labels)
             total = out[0]
