@@ -152,8 +152,8 @@ extern "C" int dtfa_bn_eval_coeffs(int C, float eps, const float* gamma, const f
 // ----------------------------------------------------------------------------
 template <bool RELU, bool RES>
 __global__ void bn_apply_kernel(const bf16* __restrict__ y, const bf16* __restrict__ res, bf16* __restrict__ z,
-                                const float* __restrict__ scale, const float* __restrict__ shift, size_t nvec,
-                                int C, int ldz) {
+                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                unsigned char* __restrict__ mask, size_t nvec, int C, int ldz) {
   // ldz: elements between consecutive output rows (== C for a dense output, larger when z is a channel
   // slice of a wider NHWC tensor, which is how branch outputs land in a concatenation without a copy)
   const int cvec = C >> 3;
@@ -168,27 +168,32 @@ __global__ void bn_apply_kernel(const bf16* __restrict__ y, const bf16* __restri
     float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
     float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
     bf16x8 o;
+    unsigned bits = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float f = (float)v[j] * sc[j] + sh[j];
       if (RES) f += (float)r[j];
       if (RELU) f = fmaxf(f, 0.f);
       o[j] = (bf16)f;
+      bits |= ((float)o[j] > 0.f ? 1u : 0u) << j;
     }
     *(bf16x8*)(z + row * ldz + c0) = o;
+    // one bit per element, (z > 0): the backward pass reads this instead of the whole activation
+    if (RELU && mask != nullptr) mask[i] = (unsigned char)bits;
   }
 }
 
 extern "C" int dtfa_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
-                             long long M, int C, int ldz, int relu, hipStream_t st) {
+                             void* mask, long long M, int C, int ldz, int relu, hipStream_t st) {
   if (C % 8 || ldz % 8 || ldz < C) return -1;
+  if (mask != nullptr && !relu) return -2;
   size_t nvec = (size_t)M * C / 8;
   if (nvec == 0) return 0;
   unsigned blocks = (unsigned)((nvec + 255) / 256);
   if (blocks > 8192) blocks = 8192;
 #define L(R_, S_)                                                                                          \
   hipLaunchKernelGGL((bn_apply_kernel<R_, S_>), dim3(blocks), dim3(256), 0, st, (const bf16*)y,            \
-                     (const bf16*)res, (bf16*)z, scale, shift, nvec, C, ldz)
+                     (const bf16*)res, (bf16*)z, scale, shift, (unsigned char*)mask, nvec, C, ldz)
   if (relu && res) L(true, true);
   else if (relu) L(true, false);
   else if (res) L(false, true);
@@ -200,7 +205,8 @@ extern "C" int dtfa_bn_apply(const void* y, const void* res, void* z, const floa
 // ----------------------------------------------------------------------------
 // Column partial sums.  Thread block = TX channel-groups (8 channels each) x
 // TY row lanes.  MODE 0: x -> (sum x, sum x^2).  MODE 1 (backward):
-//   g = dz * mask,  mask = (zout > 0) when ReLU else 1
+//   g = dz * mask,  mask = (zout > 0) [relu 1], (y*scale+shift > 0) [relu 2], a stored bitmask with one
+//   bit per element passed through ``zout`` [relu 3], else 1
 //   -> (sum g, sum g * xhat),  xhat = (y - mean) * invstd
 // Output rows: [gridDim.y][2][C].
 // ----------------------------------------------------------------------------
@@ -236,6 +242,7 @@ __global__ void col_partials_kernel(const bf16* __restrict__ a, const bf16* __re
     constexpr int U = 4;
     for (long long r = r0 + ty; r < r1; r += (long long)TY * U) {
       bf16x8 v[U], yy[U], zz[U];
+      unsigned mb[U];
       bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -246,6 +253,7 @@ __global__ void col_partials_kernel(const bf16* __restrict__ a, const bf16* __re
         if (MODE == 1) {
           yy[u] = *(const bf16x8*)(yv + off);
           if (relu == 1) zz[u] = *(const bf16x8*)(zout + off);
+          if (relu == 3) mb[u] = ((const unsigned char*)zout)[off >> 3];
         }
       }
 #pragma unroll
@@ -265,6 +273,7 @@ __global__ void col_partials_kernel(const bf16* __restrict__ a, const bf16* __re
             float yf = (float)yy[u][j];
             if (relu == 1 && !((float)zz[u][j] > 0.f)) g = 0.f;
             if (relu == 2 && !(yf * sc[j] + sh[j] > 0.f)) g = 0.f;
+            if (relu == 3 && !((mb[u] >> j) & 1u)) g = 0.f;
             float xh = (yf - mu[j]) * is[j];
             s1[j] += g;
             s2[j] += g * xh;
@@ -398,7 +407,9 @@ __global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __r
     bf16x8 g8 = *(const bf16x8*)(dz + i * 8);
     bf16x8 y8 = *(const bf16x8*)(y + i * 8);
     bf16x8 z8;
+    unsigned mb = 0;
     if (RELU == 1) z8 = *(const bf16x8*)(zout + i * 8);
+    if (RELU == 3) mb = ((const unsigned char*)zout)[i];
     float S[8], H[8];
     if (RELU == 2) {
       float4 s0 = *(const float4*)(scale + c0), s1 = *(const float4*)(scale + c0 + 4);
@@ -418,6 +429,7 @@ __global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __r
       float g = (float)g8[j];
       if (RELU == 1 && !((float)z8[j] > 0.f)) g = 0.f;
       if (RELU == 2 && !((float)y8[j] * S[j] + H[j] > 0.f)) g = 0.f;
+      if (RELU == 3 && !((mb >> j) & 1u)) g = 0.f;
       o[j] = (bf16)(A[j] * g + Bc[j] * (float)y8[j] + Cc[j]);
       if (DRES) r[j] = (bf16)g;
     }
@@ -430,7 +442,7 @@ extern "C" int dtfa_bn_bwd_apply(const void* dz, const void* y, const void* zout
                                  const float* ca, const float* cb, const float* cc, const float* scale,
                                  const float* shift, long long M, int C, int relu, hipStream_t st) {
   if (C % 8) return -1;
-  if ((relu == 1 && !zout) || (relu == 2 && (!scale || !shift))) return -2;
+  if (((relu == 1 || relu == 3) && !zout) || (relu == 2 && (!scale || !shift))) return -2;
   size_t nvec = (size_t)M * C / 8;
   if (nvec == 0) return 0;
   unsigned blocks = (unsigned)((nvec + 255) / 256);
@@ -442,9 +454,35 @@ extern "C" int dtfa_bn_bwd_apply(const void* dz, const void* y, const void* zout
   else if (relu == 1) L(1, false);
   else if (relu == 2 && dres) L(2, true);
   else if (relu == 2) L(2, false);
+  else if (relu == 3 && dres) L(3, true);
+  else if (relu == 3) L(3, false);
   else if (dres) L(0, true);
   else L(0, false);
 #undef L
+  return (int)hipGetLastError();
+}
+
+// dx = dz where the bit is set, else 0 (the masked gradient as a tensor, for consumers without a fused path).
+__global__ void mask_mul_kernel(const bf16* __restrict__ dz, const unsigned char* __restrict__ mask,
+                                bf16* __restrict__ dx, size_t nvec) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    bf16x8 g = *(const bf16x8*)(dz + i * 8);
+    unsigned mb = mask[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (!((mb >> j) & 1u)) g[j] = (bf16)0.f;
+    *(bf16x8*)(dx + i * 8) = g;
+  }
+}
+
+extern "C" int dtfa_mask_mul(const void* dz, const void* mask, void* dx, long long n, hipStream_t st) {
+  if (n % 8) return -1;
+  size_t nvec = (size_t)n / 8;
+  if (!nvec) return 0;
+  unsigned blocks = (unsigned)((nvec + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(mask_mul_kernel, dim3(blocks), dim3(256), 0, st, (const bf16*)dz, (const unsigned char*)mask,
+                     (bf16*)dx, nvec);
   return (int)hipGetLastError();
 }
 

@@ -33,6 +33,7 @@ struct ConvArgs {
   bf16* y;
   const float* bias;   // [Cout] or null
   const bf16* addend;  // optional tensor of the output's shape, added in the epilogue (residual gradient)
+  const unsigned char* addend_mask;  // optional: one bit per element of addend, only set elements are added
   float* stats;        // [mtiles*2][2][Cout] partial (sum, sumsq) or null
   const bf16* zero;    // >= 16 bytes of zeros, 16-byte aligned
   const int* taps;     // T entries, (dy << 16) | (dx & 0xffff)
@@ -325,8 +326,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       }
       if (p.addend != nullptr) {
         bf16x8 a = *(const bf16x8*)(p.addend + opixel * p.Cout + co);
+        unsigned mb = 0xffu;
+        if (p.addend_mask != nullptr) mb = p.addend_mask[(opixel * p.Cout + co) >> 3];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)a[j]);
+        for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (((mb >> j) & 1u) ? (float)a[j] : 0.f));
       }
       *(bf16x8*)(p.y + opixel * p.Cout + co) = v;
     }

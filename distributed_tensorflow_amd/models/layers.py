@@ -61,11 +61,10 @@ class ConvBnAct(nn.Module):
             if t is not None:
                 t._keep_fp32 = True
 
-    def forward(self, x, residual=None, residual_grad_slot=None, input_grad_slot=None, out=None):
+    def forward(self, x, residual=None, links=None, out=None):
         return F.conv_bn_act(x, self.weight, self.gamma, self.beta, self.running_mean, self.running_var,
                              stride=self.stride, padding=self.padding, eps=self.eps, momentum=self.momentum,
-                             relu=self.relu, training=self.training, residual=residual,
-                             residual_grad_slot=residual_grad_slot, input_grad_slot=input_grad_slot, out=out)
+                             relu=self.relu, training=self.training, residual=residual, links=links, out=out)
 
 
 class Conv2d(nn.Module):

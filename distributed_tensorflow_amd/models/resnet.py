@@ -35,11 +35,21 @@ class Bottleneck(nn.Module):
             self.shortcut = None
 
     def forward(self, x):
-        if self.shortcut is None and x.is_cuda and x.requires_grad and torch.is_grad_enabled():
-            # identity block on the GPU: the residual gradient is added inside conv1's dgrad epilogue
-            slot = F.GradSlot()
-            out = self.conv2(self.conv1(x, input_grad_slot=slot))
-            return self.conv3(out, residual=x, residual_grad_slot=slot)
+        if x.is_cuda and x.requires_grad and torch.is_grad_enabled() and self.training:
+            # Training on the GPU: the layers of the block pass gradients to each other directly instead
+            # of through autograd sums (see ops.functional.GradSlot).
+            to_conv1 = F.GradSlot()
+            if self.shortcut is None:
+                # identity block: conv1's dgrad epilogue adds the masked gradient of the block output
+                out = self.conv2(self.conv1(x, links=F.Links(input_grad=to_conv1)))
+                return self.conv3(out, residual=x, links=F.Links(residual_grad=to_conv1))
+            # projection block: the shortcut gates its incoming gradient with conv3's sign bits and hands
+            # its input gradient to conv1's dgrad epilogue.  It is called after conv2 so that its backward
+            # runs before conv1's (autograd runs later-created nodes first).
+            sign = F.GradSlot()
+            out = self.conv2(self.conv1(x, links=F.Links(input_grad=to_conv1)))
+            identity = self.shortcut(x, links=F.Links(output_mask=sign, input_grad_out=to_conv1))
+            return self.conv3(out, residual=identity, links=F.Links(residual_mask=sign))
         identity = x if self.shortcut is None else self.shortcut(x)
         out = self.conv2(self.conv1(x))
         return self.conv3(out, residual=identity)

@@ -199,7 +199,7 @@ def pick_wgrad_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
 # launches
 # --------------------------------------------------------------------------
 def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, osx, oy0, ox0, isy, isx, B,
-                  cin_magic, bias=None, relu=False, stats=False, addend=None, zero_taps=False):
+                  cin_magic, bias=None, relu=False, stats=False, addend=None, zero_taps=False, addend_mask=None):
     M = B * oyn * oxn
     K = T * cin
     bm, bn, bk, nst = pick_fwd_tile(M, cout, K)
@@ -212,6 +212,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     a.x, a.w, a.y = x.data_ptr(), w2d.data_ptr(), y.data_ptr()
     a.bias = hipk.ptr(bias)
     a.addend = hipk.ptr(addend)
+    a.addend_mask = hipk.ptr(addend_mask)
     a.stats = hipk.ptr(part)
     a.zero = hipk.zero_page(x.device).data_ptr()
     a.taps = taps.data_ptr()
@@ -257,9 +258,11 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
     return y, part
 
 
-def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Optional[torch.Tensor] = None,
+               addend_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dy [B,OH,OW,Cout] -> dx [B,IH,IW,Cin] (+ ``addend``, e.g. the gradient arriving over a
-    residual connection, fused into the epilogue instead of a separate add pass)."""
+    residual connection, fused into the epilogue instead of a separate add pass; ``addend_mask`` holds
+    one bit per element of ``addend`` and only set elements are added)."""
     hipk.require(dy, torch.bfloat16, "dy")
     hipk.require(w, torch.bfloat16, "w")
     B = dy.shape[0]
@@ -274,6 +277,10 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Option
             raise ValueError("addend shape does not match dx")
         if plan.dgrad_needs_zero:
             raise ValueError("addend fusion needs every input pixel to be written by a dgrad phase")
+        if addend_mask is not None and (addend_mask.dtype != torch.uint8 or addend_mask.numel() * 8 != addend.numel()):
+            raise ValueError("addend bitmask size mismatch")
+    elif addend_mask is not None:
+        raise ValueError("addend_mask without addend")
     if plan.dgrad_needs_zero:
         dx = torch.zeros((B, plan.ih, plan.iw, plan.cin), dtype=torch.bfloat16, device=dy.device)
     else:
@@ -284,7 +291,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Option
                                          plan.cin, ph.T, hipk.stream()), "weight_permute")
         _launch_igemm(dy, wd, dx, ph.taps, ph.T, plan.oh, plan.ow, plan.cout, plan.ih, plan.iw, plan.cin,
                       ph.OYn, ph.OXn, plan.sy, plan.sx, ph.oy0, ph.ox0, 1, 1, B, plan.cout_magic, addend=addend,
-                      zero_taps=plan.is_pointwise)
+                      zero_taps=plan.is_pointwise, addend_mask=addend_mask)
     return dx
 
 

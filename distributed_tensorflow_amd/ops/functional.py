@@ -99,19 +99,51 @@ def _deliver_wgrad(param, x, dy, plan):
 
 
 class GradSlot:
-    """Side channel for the gradient of a residual (identity) connection.
+    """Side channel between the backward passes of two layers of a residual block.
 
-    In ``out = act(bn(conv3(h)) + x)`` with ``h = f(conv1(x))`` the gradient of ``x`` is
-    ``dgrad(conv1) + g`` where ``g`` is the masked incoming gradient.  Letting autograd sum the two
-    costs a full read-read-write pass over the activation; instead the layer that consumes the
-    residual parks ``g`` here during its backward and the layer that first consumed ``x`` adds it
-    inside the epilogue of its data-gradient kernel.  Dependencies guarantee the order: the
-    residual consumer's backward always runs before the backward of anything upstream of it."""
+    In ``out = relu(bn(conv3(h)) + r)`` the gradient that flows into the residual ``r`` is
+    ``g = dout * (out > 0)``.  Letting autograd materialise and sum such tensors costs full passes
+    over the activation; instead layers hand each other what they need through a slot:
 
-    __slots__ = ("grad",)
+    * ``grad`` (+ ``mask``): a gradient tensor for another layer to add inside the epilogue of its
+      data-gradient kernel; with ``mask`` (one bit per element) only the set elements are added, so
+      ``g`` itself is never written -- the incoming ``dout`` and the stored sign bits are enough;
+    * ``mask`` alone: the sign bits of the activation a layer's output was added into; that layer's
+      batch-norm backward gates its incoming gradient with them.
+
+    Producers run before consumers by data dependency, except for ``input_grad_out_slot`` (a sibling
+    branch): there ``consumed`` tells the producer that the consumer already ran, and it falls back to
+    returning its gradient through autograd."""
+
+    __slots__ = ("grad", "mask", "consumed")
 
     def __init__(self):
         self.grad = None
+        self.mask = None
+        self.consumed = False
+
+    def take(self):
+        g, m = self.grad, self.mask
+        self.grad = self.mask = None
+        self.consumed = True
+        return g, m
+
+
+class Links:
+    """The slots of one conv + batch-norm layer (all optional)."""
+
+    __slots__ = ("residual_grad", "residual_mask", "input_grad", "output_mask", "input_grad_out")
+
+    def __init__(self, residual_grad=None, residual_mask=None, input_grad=None, output_mask=None,
+                 input_grad_out=None):
+        self.residual_grad = residual_grad      # park (dout, mask) of the residual for an upstream dgrad epilogue
+        self.residual_mask = residual_mask      # park the mask for the layer that produced the residual
+        self.input_grad = input_grad            # add this to the input gradient inside the dgrad epilogue
+        self.output_mask = output_mask          # gate the incoming gradient with this mask
+        self.input_grad_out = input_grad_out    # park the input gradient here instead of returning it
+
+
+_NO_LINKS = Links()
 
 
 # ----------------------------------------------------------------------------
@@ -120,7 +152,7 @@ class GradSlot:
 class _ConvBnActFn(Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, plan, run_mean, run_var, eps, momentum, relu, training,
-                params, res_slot=None, in_slot=None):
+                params, links):
         need_grad = any(ctx.needs_input_grad)
         y, part = cv.conv_fwd(x, weight, plan, want_stats=training)
         M = y.numel() // plan.cout
@@ -129,28 +161,39 @@ class _ConvBnActFn(Function):
         else:
             scale, shift = K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
             mean = invstd = None
-        z = K.bn_apply(y, scale, shift, relu, residual)
+        # ReLU backward needs the sign of the output only.  Without a residual it is recomputed from y;
+        # with one it is stored as a bitmask (1/16 of the activation's bytes) written by the same pass.
+        want_mask = need_grad and training and relu and residual is not None
+        if want_mask:
+            z, mask = K.bn_apply(y, scale, shift, relu, residual, want_mask=True)
+        else:
+            z, mask = K.bn_apply(y, scale, shift, relu, residual), None
         ctx.plan, ctx.relu, ctx.training = plan, relu, training
         ctx.has_res = residual is not None
         ctx.params = params  # (weight_param, gamma_param, beta_param) python objects
-        ctx.res_slot, ctx.in_slot = res_slot, in_slot
+        ctx.links = links
         if need_grad:
-            # the ReLU mask is recomputed from y when nothing was added before the activation
-            keep_z = relu and (residual is not None or not training)
-            ctx.save_for_backward(x, weight, y, z if keep_z else None, gamma, mean, invstd, scale, shift)
+            keep_z = relu and not training
+            ctx.save_for_backward(x, weight, y, z if keep_z else None, mask, gamma, mean, invstd, scale, shift)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, weight, y, z, gamma, mean, invstd, scale, shift = ctx.saved_tensors
-        plan = ctx.plan
+        x, weight, y, z, mask, gamma, mean, invstd, scale, shift = ctx.saved_tensors
+        plan, links = ctx.plan, ctx.links
         wparam, gparam, bparam = ctx.params
         dz = dz.contiguous()
         want_dres = ctx.has_res and ctx.needs_input_grad[4]
-        addend = None
-        if ctx.in_slot is not None:
-            addend, ctx.in_slot.grad = ctx.in_slot.grad, None
+        addend = addend_mask = None
+        if links.input_grad is not None:
+            addend, addend_mask = links.input_grad.take()
+        gate = mask
+        if links.output_mask is not None and links.output_mask.mask is not None:
+            if mask is not None:
+                raise ValueError("a layer with its own residual ReLU cannot also be gated from outside")
+            gate, links.output_mask.mask = links.output_mask.mask, None
         direct = False
+        dres = None
         if ctx.training:
             # per-channel gradients go straight into the flat gradient buffer when both parameters live there
             g_mg = getattr(gparam, "main_grad", None) if (gamma is not None and ctx.needs_input_grad[2]) else None
@@ -159,14 +202,30 @@ class _ConvBnActFn(Function):
             direct = (b_mg is not None and b_mg.dtype == torch.float32
                       and (gamma is None or (g_mg is not None and g_mg.dtype == torch.float32
                                              and getattr(gparam, "_grad_filled", False) == filled)))
-            dy, dres, dgamma, dbeta = K.bn_backward(dz, y, z, mean, invstd, gamma, ctx.relu, want_dres,
-                                                    dgamma_out=g_mg if direct else None,
-                                                    dbeta_out=b_mg if direct else None,
-                                                    accumulate=filled if direct else False,
-                                                    scale=scale, shift=shift)
+            dy, _, dgamma, dbeta = K.bn_backward(dz, y, None, mean, invstd, gamma, ctx.relu, False,
+                                                 dgamma_out=g_mg if direct else None,
+                                                 dbeta_out=b_mg if direct else None,
+                                                 accumulate=filled if direct else False,
+                                                 scale=scale, shift=shift, mask=gate)
+            if want_dres:
+                if mask is None:
+                    dres = dz  # no activation between the sum and this layer's output
+                elif links.residual_grad is not None:
+                    links.residual_grad.grad, links.residual_grad.mask = dz, mask
+                elif links.residual_mask is not None:
+                    links.residual_mask.mask = mask
+                    dres = dz  # the producer of the residual gates it with the parked mask
+                else:
+                    dres = K.mask_mul(dz, mask)
         else:
             g = K.relu_bwd(dz, z) if ctx.relu else dz
-            dres = g if want_dres else None
+            if gate is not None and gate is not mask:
+                g = K.mask_mul(g, gate)
+            if want_dres:
+                if links.residual_grad is not None:
+                    links.residual_grad.grad = g
+                else:
+                    dres = g
             dy = (g.float() * scale).to(BF16)
             dgamma = dbeta = None
             if gamma is not None and ctx.needs_input_grad[2]:
@@ -184,15 +243,17 @@ class _ConvBnActFn(Function):
             if ctx.needs_input_grad[3]:
                 gb = _deliver_small(bparam, dbeta) if bparam is not None else dbeta
         if ctx.needs_input_grad[0]:
-            gx = cv.conv_dgrad(dy, weight, plan, addend=addend)
-        if ctx.res_slot is not None and dres is not None:
-            ctx.res_slot.grad, dres = dres, None  # picked up by the upstream layer's dgrad epilogue
-        return gx, gw, gg, gb, dres, None, None, None, None, None, None, None, None, None, None
+            gx = cv.conv_dgrad(dy, weight, plan, addend=addend, addend_mask=addend_mask)
+            out_slot = links.input_grad_out
+            if out_slot is not None and not out_slot.consumed:
+                out_slot.grad, gx = gx, None  # a sibling consumer of x adds it in its own dgrad epilogue
+        return gx, gw, gg, gb, dres, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, eps, momentum, relu, training,
-                residual=None, residual_grad_slot=None, input_grad_slot=None, out=None):
+                residual=None, links=None, out=None):
     """``act(bn(conv(x, weight)) + residual)``; batch statistics when ``training``.
+    ``links`` (:class:`Links`) wires the layer's backward pass to its neighbours in a residual block.
 
     ``out`` (device path, nothing requiring grad) is a channel slice of a wider NHWC tensor that
     receives the result directly -- the way parallel branches are concatenated without a copy."""
@@ -220,10 +281,11 @@ def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, e
             z = z + residual
         return torch.relu(z) if relu else z
     plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], weight.shape[0], kh, kw, sy, sx, pads, x.device)
-    if input_grad_slot is not None and (plan.dgrad_needs_zero or not x.requires_grad):
-        raise ValueError("input_grad_slot needs an input that requires grad and a dgrad that writes every pixel")
+    links = links if links is not None else _NO_LINKS
+    if links.input_grad is not None and (plan.dgrad_needs_zero or not x.requires_grad):
+        raise ValueError("input_grad needs an input that requires grad and a dgrad that writes every pixel")
     return _ConvBnActFn.apply(x, weight, gamma, beta, residual, plan, run_mean, run_var, eps, momentum, relu,
-                              training, (weight, gamma, beta), residual_grad_slot, input_grad_slot)
+                              training, (weight, gamma, beta), links)
 
 
 # ----------------------------------------------------------------------------

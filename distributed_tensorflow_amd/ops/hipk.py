@@ -23,7 +23,7 @@ c_float = C.c_float
 
 class ConvArgs(C.Structure):
     _fields_ = [
-        ("x", c_void), ("w", c_void), ("y", c_void), ("bias", c_void), ("addend", c_void), ("stats", c_void),
+        ("x", c_void), ("w", c_void), ("y", c_void), ("bias", c_void), ("addend", c_void), ("addend_mask", c_void), ("stats", c_void),
         ("zero", c_void), ("taps", c_void),
         ("IH", c_int), ("IW", c_int), ("Cin", c_int),
         ("OH", c_int), ("OW", c_int), ("Cout", c_int),
@@ -80,7 +80,7 @@ class _Sigs:
     dtfa_bn_finalize = [c_void, c_int, c_int, c_float, c_float, c_void, c_void, c_void, c_void, c_void, c_void,
                         c_void, c_void, c_float, c_void]
     dtfa_bn_eval_coeffs = [c_int, c_float, c_void, c_void, c_void, c_void, c_void, c_void, c_void]
-    dtfa_bn_apply = [c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_int, c_void]
+    dtfa_bn_apply = [c_void, c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_int, c_void]
     dtfa_col_partials_rows = [c_ll, c_int]
     dtfa_bn_stats_partials = [c_void, c_void, c_ll, c_int, c_void]
     dtfa_bn_bwd_partials = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_void]
@@ -102,6 +102,7 @@ class _Sigs:
     dtfa_adam = [c_void, c_void, c_void, c_void, c_int, c_void, c_ll, c_void, c_float, c_float, c_float, c_void]
     dtfa_momentum = [c_void, c_void, c_void, c_int, c_void, c_ll, c_void, c_float, c_float, c_int, c_void]
     dtfa_cast_f32_bf16 = [c_void, c_void, c_ll, c_void]
+    dtfa_mask_mul = [c_void, c_void, c_void, c_ll, c_void]
     dtfa_set_hyper = [c_void, c_float, c_float, c_void]
     dtfa_weight_permute = [c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_void]
     dtfa_dropout = [c_void, c_void, c_ll, C.c_ulonglong, c_void, c_float, c_void]

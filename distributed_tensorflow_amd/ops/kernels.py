@@ -89,8 +89,11 @@ def channel_slice_pitch(out: torch.Tensor, like: torch.Tensor) -> int:
 
 
 def bn_apply(y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool,
-             residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``act(y*scale + shift (+ residual))``; ``out`` may be a channel slice of a wider NHWC tensor."""
+             residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+             want_mask: bool = False):
+    """``act(y*scale + shift (+ residual))``; ``out`` may be a channel slice of a wider NHWC tensor.
+    With ``want_mask`` (ReLU only) also returns the activation's sign as one bit per element
+    (uint8 [numel / 8]), which is all the backward pass needs of the output: ``(z, mask)``."""
     hipk.require(y, BF16, "y")
     M, Cc = _as2d(y)
     if scale.numel() != Cc or shift.numel() != Cc:
@@ -103,14 +106,24 @@ def bn_apply(y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bo
         z, ldz = torch.empty_like(y), Cc
     else:
         z, ldz = out, channel_slice_pitch(out, y)
+    mask = None
+    if want_mask:
+        if not relu or out is not None:
+            raise ValueError("the sign bitmask needs a ReLU and a dense output")
+        mask = torch.empty(y.numel() // 8, dtype=torch.uint8, device=y.device)
     hipk.check(hipk.lib().dtfa_bn_apply(y.data_ptr(), hipk.ptr(residual), z.data_ptr(), scale.data_ptr(),
-                                        shift.data_ptr(), M, Cc, ldz, 1 if relu else 0, hipk.stream()), "bn_apply")
-    return z
+                                        shift.data_ptr(), hipk.ptr(mask), M, Cc, ldz, 1 if relu else 0,
+                                        hipk.stream()), "bn_apply")
+    return (z, mask) if want_mask else z
 
 
 def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, dgamma_out=None, dbeta_out=None,
-                accumulate=False, scale=None, shift=None):
+                accumulate=False, scale=None, shift=None, mask=None):
     """Returns (dy, dres or None, dgamma, dbeta).
+
+    ``mask`` (uint8, one bit per element) gates ``dz`` -- the stored sign of a ReLU output, this layer's
+    own or that of the activation this layer's output was added into -- and takes precedence over
+    ``relu`` / ``zout``.
 
     With ``relu`` the activation mask is taken from ``zout`` (the stored
     activation output) when it is given, otherwise it is recomputed from
@@ -121,7 +134,11 @@ def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, d
     if dz.shape != y.shape:
         raise ValueError("dz/y shape mismatch")
     mode = 0
-    if relu:
+    if mask is not None:
+        if mask.dtype != torch.uint8 or mask.numel() * 8 != y.numel() or not mask.is_contiguous():
+            raise ValueError("bitmask size mismatch")
+        mode = 3
+    elif relu:
         if zout is not None:
             hipk.require(zout, BF16, "zout")
             if zout.shape != y.shape:
@@ -135,7 +152,7 @@ def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, d
     L = hipk.lib()
     rows = L.dtfa_col_partials_rows(M, Cc)
     part = torch.empty((rows, 2, Cc), dtype=F32, device=y.device)
-    zp = hipk.ptr(zout) if mode == 1 else None
+    zp = hipk.ptr(zout) if mode == 1 else (mask.data_ptr() if mode == 3 else None)
     sp = scale.data_ptr() if mode == 2 else None
     hp = shift.data_ptr() if mode == 2 else None
     hipk.check(L.dtfa_bn_bwd_partials(dz.data_ptr(), y.data_ptr(), zp, mean.data_ptr(), invstd.data_ptr(), sp, hp,
@@ -160,6 +177,17 @@ def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, d
                                    coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), sp, hp, M, Cc, mode,
                                    hipk.stream()), "bn_bwd_apply")
     return dy, dres, dgamma, dbeta
+
+
+def mask_mul(dz: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """``dz`` where the bit of ``mask`` is set, zero elsewhere."""
+    hipk.require(dz, BF16, "dz")
+    if mask.dtype != torch.uint8 or mask.numel() * 8 != dz.numel():
+        raise ValueError("bitmask size mismatch")
+    out = torch.empty_like(dz)
+    hipk.check(hipk.lib().dtfa_mask_mul(dz.data_ptr(), mask.data_ptr(), out.data_ptr(), dz.numel(), hipk.stream()),
+               "mask_mul")
+    return out
 
 
 def relu_bwd(dz: torch.Tensor, z: torch.Tensor) -> torch.Tensor:

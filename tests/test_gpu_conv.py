@@ -103,3 +103,21 @@ def test_conv_large_tiles():
     dw = cv.conv_wgrad(xb.cuda(), dy.cuda(), plan)
     assert (dx.float().cpu() - xr.grad).abs().max().item() <= 2e-2 * xr.grad.abs().max().item()
     assert (dw.cpu() - wr.grad).abs().max().item() <= 2e-2 * wr.grad.abs().max().item()
+
+
+def test_dgrad_masked_addend():
+    """The dgrad epilogue adds only the elements of ``addend`` whose bit is set."""
+    case = (2, 14, 14, 64, 32, 1, 1, 1, 1, "VALID")
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case)
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    g = torch.Generator().manual_seed(11)
+    dy = torch.randn(B, plan.oh, plan.ow, Cout, generator=g).bfloat16().cuda()
+    add = torch.randn(B, H, W, Cin, generator=g).bfloat16().cuda()
+    keep = torch.rand(B, H, W, Cin, generator=g).cuda() > 0.5
+    mask = (keep.view(-1, 8).to(torch.uint8) << torch.arange(8, device="cuda", dtype=torch.uint8)).sum(1).to(torch.uint8)
+    base = cv.conv_dgrad(dy, w.bfloat16().cuda(), plan)
+    got = cv.conv_dgrad(dy, w.bfloat16().cuda(), plan, addend=add, addend_mask=mask)
+    want = (base.float() + torch.where(keep, add.float(), torch.zeros_like(add, dtype=torch.float32))).bfloat16()
+    # the kernel adds before rounding the data-gradient to bf16; allow one rounding step of difference
+    torch.testing.assert_close(got.float(), want.float(), rtol=1e-2, atol=1e-2)

@@ -58,6 +58,16 @@ def test_bn_forward_backward(shape, relu, res):
     torch.testing.assert_close(dbeta.cpu(), bf.grad, rtol=2e-2, atol=2e-2 * bf.grad.abs().max().item())
     if res:
         assert (dres.float().cpu() - rf.grad).abs().max().item() <= 2e-2 * rf.grad.abs().max().item()
+    if relu:
+        # the stored sign bitmask is an exact substitute for reading the activation output
+        z2, mask = K.bn_apply(yc, sc, sh, True, r.cuda() if res else None, want_mask=True)
+        assert torch.equal(z2, z) and mask.dtype == torch.uint8 and mask.numel() * 8 == z.numel()
+        bits = ((mask.view(-1, 1) >> torch.arange(8, device="cuda", dtype=torch.uint8)) & 1).bool().view(z.shape)
+        assert torch.equal(bits, z > 0)
+        dy_z, dres_z, dg_z, db_z = K.bn_backward(dz.cuda(), yc, z, m, i, gamma.cuda(), True, True)
+        dy_m, _, dg_m, db_m = K.bn_backward(dz.cuda(), yc, None, m, i, gamma.cuda(), True, False, mask=mask)
+        assert torch.equal(dy_z, dy_m) and torch.equal(dg_z, dg_m) and torch.equal(db_z, db_m)
+        assert torch.equal(K.mask_mul(dz.cuda(), mask), dres_z)
 
 
 def test_bn_eval_coeffs():
