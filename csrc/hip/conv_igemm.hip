@@ -47,6 +47,16 @@ struct ConvArgs {
   int relu;
   int dense_out;       // output pixel index == m (no stride/offset mapping)
   int pointwise;       // 1x1, stride 1, no padding, dense output: input pixel index == m
+  // Data-gradient launches whose output is the incoming gradient dz of a batch-norm layer can emit that
+  // layer's backward partial sums (sum g, sum g*xhat; g = dz gated by the ReLU sign, xhat = (y-mean)*invstd)
+  // into ``stats`` while the output tile is still on chip:
+  const bf16* bn_y;              // the batch-norm input (shape of the output), or null
+  const float* bn_mean;          // [Cout]
+  const float* bn_invstd;        // [Cout]
+  const float* bn_scale;         // [Cout]  (bn_relu == 2: sign recomputed from y*scale+shift)
+  const float* bn_shift;         // [Cout]
+  const unsigned char* bn_mask;  // one bit per output element (bn_relu == 3)
+  int bn_relu;                   // 0: no gating, 2: recompute, 3: stored bits
 };
 
 #define MAX_TAPS 64
@@ -59,7 +69,8 @@ __device__ __forceinline__ int swz_of_row(int row) {
 }
 
 // EPI selects the epilogue at compile time: 0 = plain store (data-gradient, no statistics),
-// 1 = batch-norm partial statistics, 2 = bias (+ optional ReLU).
+// 1 = batch-norm partial statistics, 2 = bias (+ optional ReLU), 3 = data-gradient that also emits the
+// batch-norm backward partial sums of the layer its output flows into.
 // Timing-only builds for attributing main-loop time (results are wrong): -DDTFA_DBG=1 drops the global
 // loads of the main loop, =2 replaces the MFMAs by one scalar FMA per fragment pair, =3 both.
 #ifndef DTFA_DBG
@@ -67,7 +78,7 @@ __device__ __forceinline__ int swz_of_row(int row) {
 #endif
 
 template <int BM, int BN, int BK, int EPI, int NST>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs p) {
   constexpr int S = BK / 8;            // 16-byte slots per LDS row
   constexpr int ROWB = BK * 2;         // bytes per LDS row
   constexpr int RPI = 1024 / ROWB;     // rows covered by one wave-instruction
@@ -266,6 +277,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   __syncthreads();  // all fragment reads done before the tiles are reused by the epilogue
 
   // ---- epilogue: bias / relu / bn partial statistics / bf16 rows via LDS ----
+  // Row readback geometry: a wave-instruction covers RPP rows x CPR 16-byte chunks; lane -> (row, chunk)
+  // is the same in every pass, so a lane keeps one chunk column (8 channels).
+  constexpr int CPR = WN / 8;         // 16-byte chunks per row
+  constexpr int RPP = 64 / CPR;       // rows per pass
+  constexpr int NP = WM / RPP;        // passes
+  const int chunk_co = n0 + wc * WN + (lane % CPR) * 8;
+  auto out_offset = [&](int pass, bool& ok) -> size_t {
+    const int m = m0 + wr * WM + pass * RPP + lane / CPR;
+    ok = m < p.M && chunk_co < p.Cout;
+    size_t opixel = 0;
+    if (ok) {
+      if (p.dense_out) {
+        opixel = (size_t)m;
+      } else {
+        int b = m / opix;
+        int rem = m - b * opix;
+        int oy = rem / p.OXn;
+        int ox = rem - oy * p.OXn;
+        opixel = ((size_t)b * p.OH + (oy * p.osy + p.oy0)) * p.OW + (ox * p.osx + p.ox0);
+      }
+    }
+    return opixel * p.Cout + chunk_co;
+  };
   char* ep = lds_tiles + wid * (WM * EP_PITCH);
   const int colq = lane & 31;
 #pragma unroll
@@ -304,34 +338,97 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   }
   __syncthreads();
 
-  constexpr int CPR = WN / 8;         // 16-byte chunks per row
-  constexpr int RPP = 64 / CPR;       // rows per pass
+  float bs1[8], bs2[8], bmu[8], bis[8], bsc[8], bsh[8];
+  if (EPI == 3) {
 #pragma unroll
-  for (int pass = 0; pass < WM / RPP; ++pass) {
-    int r = pass * RPP + lane / CPR;
-    int c = lane % CPR;
-    int m = m0 + wr * WM + r;
-    int co = n0 + wc * WN + c * 8;
-    if (m < p.M && co < p.Cout) {
-      bf16x8 v = *(const bf16x8*)(ep + r * EP_PITCH + c * 16);
-      size_t opixel;
-      if (p.dense_out) {
-        opixel = (size_t)m;
-      } else {
-        int b = m / opix;
-        int rem = m - b * opix;
-        int oy = rem / p.OXn;
-        int ox = rem - oy * p.OXn;
-        opixel = ((size_t)b * p.OH + (oy * p.osy + p.oy0)) * p.OW + (ox * p.osx + p.ox0);
-      }
-      if (p.addend != nullptr) {
-        bf16x8 a = *(const bf16x8*)(p.addend + opixel * p.Cout + co);
-        unsigned mb = 0xffu;
-        if (p.addend_mask != nullptr) mb = p.addend_mask[(opixel * p.Cout + co) >> 3];
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = chunk_co + j < p.Cout;
+      bs1[j] = bs2[j] = 0.f;
+      bmu[j] = ok ? p.bn_mean[chunk_co + j] : 0.f;
+      bis[j] = ok ? p.bn_invstd[chunk_co + j] : 0.f;
+      bsc[j] = (ok && p.bn_relu == 2) ? p.bn_scale[chunk_co + j] : 0.f;
+      bsh[j] = (ok && p.bn_relu == 2) ? p.bn_shift[chunk_co + j] : 0.f;
+    }
+  }
+  if (EPI == 1 || EPI == 2) {
+    // forward: plain coalesced row stores
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (((mb >> j) & 1u) ? (float)a[j] : 0.f));
+    for (int pass = 0; pass < NP; ++pass) {
+      bool ok;
+      const size_t off = out_offset(pass, ok);
+      if (ok) {
+        const int r = pass * RPP + lane / CPR;
+        *(bf16x8*)(p.y + off) = *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16);
       }
-      *(bf16x8*)(p.y + opixel * p.Cout + co) = v;
+    }
+  } else {
+    // data gradient: the readback may add a residual gradient (optionally gated by a bitmask) and fold
+    // the batch-norm backward sums.  Passes are handled in groups: all global loads of a group are
+    // requested before any is consumed, so a tile pays the memory latency once per group, not per pass.
+    constexpr int G = NP >= 4 ? 4 : NP;
+    const bool has_add = p.addend != nullptr;
+    const bool has_addm = p.addend_mask != nullptr;
+#pragma unroll
+    for (int g0 = 0; g0 < NP; g0 += G) {
+      size_t ooff[G];
+      bool ook[G];
+      bf16x8 addv[G], bnyv[G];
+      unsigned addm[G], bnm[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        ooff[i] = out_offset(g0 + i, ook[i]);
+        const size_t off = ook[i] ? ooff[i] : 0;  // idle lanes read an in-range dummy
+        if (has_add) {
+          addv[i] = *(const bf16x8*)(p.addend + off);
+          addm[i] = has_addm ? (unsigned)p.addend_mask[off >> 3] : 0xffu;
+        }
+        if (EPI == 3) {
+          bnyv[i] = *(const bf16x8*)(p.bn_y + off);
+          bnm[i] = p.bn_relu == 3 ? (unsigned)p.bn_mask[off >> 3] : 0xffu;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        if (!ook[i]) continue;
+        const int r = (g0 + i) * RPP + lane / CPR;
+        bf16x8 v = *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16);
+        if (has_add) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (((addm[i] >> j) & 1u) ? (float)addv[i][j] : 0.f));
+        }
+        *(bf16x8*)(p.y + ooff[i]) = v;
+        if (EPI == 3) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float yf = (float)bnyv[i][j];
+            float g = (float)v[j];  // the rounded value, the one the elementwise backward pass will read
+            if (p.bn_relu == 2 && !(yf * bsc[j] + bsh[j] > 0.f)) g = 0.f;
+            if (!((bnm[i] >> j) & 1u)) g = 0.f;
+            bs1[j] += g;
+            bs2[j] += g * ((yf - bmu[j]) * bis[j]);
+          }
+        }
+      }
+    }
+  }
+  if (EPI == 3) {
+    // lanes that share a chunk column differ in the lane bits above log2(CPR): fold those
+#pragma unroll
+    for (int sh = CPR; sh < 64; sh <<= 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bs1[j] += __shfl_xor(bs1[j], sh, 64);
+        bs2[j] += __shfl_xor(bs2[j], sh, 64);
+      }
+    }
+    const int co = chunk_co;
+    if (lane < CPR && co < p.Cout) {
+      size_t prow = (size_t)(tile_m * 2 + wr) * 2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        p.stats[prow * p.Cout + co + j] = bs1[j];
+        p.stats[(prow + 1) * p.Cout + co + j] = bs2[j];
+      }
     }
   }
 }
@@ -355,6 +452,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
 
 template <int BM, int BN, int BK, int NST>
 static int launch_conv_epi(const ConvArgs& a, hipStream_t stream) {
+  if (a.bn_y != nullptr) return launch_conv<BM, BN, BK, 3, NST>(a, stream);
   if (a.stats != nullptr) return launch_conv<BM, BN, BK, 1, NST>(a, stream);
   if (a.bias != nullptr || a.relu) return launch_conv<BM, BN, BK, 2, NST>(a, stream);
   return launch_conv<BM, BN, BK, 0, NST>(a, stream);
@@ -367,6 +465,13 @@ extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int ns
   if (a->Cin % 8 != 0 || a->Cout % 8 != 0 || a->T > MAX_TAPS || a->T < 1) return -1;
   if (a->K != a->T * a->Cin || a->K >= (1 << 16)) return -2;
   if (a->stats != nullptr && a->bias != nullptr) return -4;
+  if (a->addend != nullptr && (a->bias != nullptr || a->relu || (a->stats != nullptr && a->bn_y == nullptr))) return -4;
+  if (a->bn_y != nullptr) {
+    if (a->stats == nullptr || a->bn_mean == nullptr || a->bn_invstd == nullptr || a->bias != nullptr || a->relu) return -5;
+    if (a->bn_relu == 2 && (a->bn_scale == nullptr || a->bn_shift == nullptr)) return -5;
+    if (a->bn_relu == 3 && a->bn_mask == nullptr) return -5;
+    if (a->bn_relu != 0 && a->bn_relu != 2 && a->bn_relu != 3) return -5;
+  }
   if (a->M <= 0) return 0;
 #define CASE(BM_, BN_, BK_)                                                                   \
   if (bm == BM_ && bn == BN_ && bk == BK_) {                                                  \

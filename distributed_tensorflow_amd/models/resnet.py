@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from ..ops import conv as cv
 from ..ops import functional as F
 from .layers import ConvBnAct, Dense
 
@@ -34,22 +35,30 @@ class Bottleneck(nn.Module):
         else:
             self.shortcut = None
 
-    def forward(self, x):
+    def forward(self, x, in_tap=None, out_tap=None):
+        """``in_tap`` / ``out_tap`` (GPU training): batch-norm backward taps shared with the previous /
+        next block -- ``in_tap`` belongs to the layer that produced ``x``, ``out_tap`` is filled by conv3."""
         if x.is_cuda and x.requires_grad and torch.is_grad_enabled() and self.training:
             # Training on the GPU: the layers of the block pass gradients to each other directly instead
-            # of through autograd sums (see ops.functional.GradSlot).
+            # of through autograd sums (see ops.functional.GradSlot), and every data-gradient kernel emits
+            # the batch-norm backward reduction of the layer below it (conv.BnBackwardTap).
             to_conv1 = F.GradSlot()
+            tap1, tap2 = cv.BnBackwardTap(), cv.BnBackwardTap()
             if self.shortcut is None:
                 # identity block: conv1's dgrad epilogue adds the masked gradient of the block output
-                out = self.conv2(self.conv1(x, links=F.Links(input_grad=to_conv1)))
-                return self.conv3(out, residual=x, links=F.Links(residual_grad=to_conv1))
+                h = self.conv1(x, links=F.Links(input_grad=to_conv1, input_tap=in_tap, output_tap=tap1))
+                h = self.conv2(h, links=F.Links(input_tap=tap1, output_tap=tap2))
+                return self.conv3(h, residual=x, links=F.Links(residual_grad=to_conv1, input_tap=tap2,
+                                                               output_tap=out_tap))
             # projection block: the shortcut gates its incoming gradient with conv3's sign bits and hands
             # its input gradient to conv1's dgrad epilogue.  It is called after conv2 so that its backward
             # runs before conv1's (autograd runs later-created nodes first).
             sign = F.GradSlot()
-            out = self.conv2(self.conv1(x, links=F.Links(input_grad=to_conv1)))
+            h = self.conv1(x, links=F.Links(input_grad=to_conv1, input_tap=in_tap, output_tap=tap1))
+            h = self.conv2(h, links=F.Links(input_tap=tap1, output_tap=tap2))
             identity = self.shortcut(x, links=F.Links(output_mask=sign, input_grad_out=to_conv1))
-            return self.conv3(out, residual=identity, links=F.Links(residual_mask=sign))
+            return self.conv3(h, residual=identity, links=F.Links(residual_mask=sign, input_tap=tap2,
+                                                                  output_tap=out_tap))
         identity = x if self.shortcut is None else self.shortcut(x)
         out = self.conv2(self.conv1(x))
         return self.conv3(out, residual=identity)
@@ -67,13 +76,17 @@ class ResNet50(nn.Module):
                 scope = "%s/block%d/unit_%d/bottleneck_v1" % (root, bi, ui + 1)
                 blocks.append(Bottleneck(cin, width, stride if ui == 0 else 1, scope, zero_init_residual))
                 cin = width * 4
-        self.blocks = nn.Sequential(*blocks)
+        self.blocks = nn.ModuleList(blocks)
         self.fc = Dense(2048, num_classes, tf_scope=root + "/logits")
 
     def forward(self, x):
         """x: [B, H, W, 8] -> logits [B, padded classes] (first ``num_classes`` columns are real)."""
         x = self.stem(x)
         x = F.max_pool(x, (3, 3), (2, 2), (1, 1, 1, 1))
-        x = self.blocks(x)
+        tap = None
+        for i, block in enumerate(self.blocks):
+            nxt = cv.BnBackwardTap() if (x.is_cuda and i + 1 < len(self.blocks)) else None
+            x = block(x, in_tap=tap, out_tap=nxt)
+            tap = nxt
         x = F.global_avg_pool(x)
         return self.fc(x)

@@ -199,13 +199,14 @@ def pick_wgrad_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
 # launches
 # --------------------------------------------------------------------------
 def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, osx, oy0, ox0, isy, isx, B,
-                  cin_magic, bias=None, relu=False, stats=False, addend=None, zero_taps=False, addend_mask=None):
+                  cin_magic, bias=None, relu=False, stats=False, addend=None, zero_taps=False, addend_mask=None,
+                  bn_tap=None):
     M = B * oyn * oxn
     K = T * cin
     bm, bn, bk, nst = pick_fwd_tile(M, cout, K)
     L = hipk.lib()
     part = None
-    if stats:
+    if stats or bn_tap is not None:
         rows = L.dtfa_conv_stats_rows(M, bm)
         part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
     a = hipk.ConvArgs()
@@ -213,6 +214,10 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     a.bias = hipk.ptr(bias)
     a.addend = hipk.ptr(addend)
     a.addend_mask = hipk.ptr(addend_mask)
+    if bn_tap is not None:
+        a.bn_y, a.bn_mean, a.bn_invstd = bn_tap.y.data_ptr(), bn_tap.mean.data_ptr(), bn_tap.invstd.data_ptr()
+        a.bn_scale, a.bn_shift, a.bn_mask = hipk.ptr(bn_tap.scale), hipk.ptr(bn_tap.shift), hipk.ptr(bn_tap.mask)
+        a.bn_relu = bn_tap.relu_mode
     a.stats = hipk.ptr(part)
     a.zero = hipk.zero_page(x.device).data_ptr()
     a.taps = taps.data_ptr()
@@ -258,8 +263,46 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
     return y, part
 
 
+class BnBackwardTap:
+    """What a data-gradient kernel needs to emit the backward partial sums of the batch-norm layer its
+    output flows into: that layer's input ``y`` and statistics, and how its ReLU sign is obtained
+    (``relu_mode`` 0: no activation, 2: recomputed from ``y*scale+shift``, 3: stored bits in ``mask``).
+    The producer of the gradient stores the partial sums in ``partials``."""
+
+    __slots__ = ("y", "mean", "invstd", "scale", "shift", "mask", "relu_mode", "partials")
+
+    def __init__(self):
+        self.y = self.mean = self.invstd = self.scale = self.shift = self.mask = self.partials = None
+        self.relu_mode = 0
+
+    @property
+    def armed(self) -> bool:
+        return self.y is not None
+
+    def clear(self) -> None:
+        """Drop the tensor references (the autograd graph may outlive the backward pass of a layer)."""
+        self.y = self.mean = self.invstd = self.scale = self.shift = self.mask = self.partials = None
+
+    def validate(self, shape, channels: int) -> None:
+        if tuple(self.y.shape) != tuple(shape) or self.y.dtype != torch.bfloat16 or not self.y.is_contiguous():
+            raise ValueError("batch-norm tap does not match the gradient's shape")
+        for t in (self.mean, self.invstd) + ((self.scale, self.shift) if self.relu_mode == 2 else ()):
+            if t is None or t.dtype != torch.float32 or t.numel() != channels:
+                raise ValueError("batch-norm tap statistics have the wrong size")
+        if self.relu_mode == 3 and (self.mask is None or self.mask.dtype != torch.uint8
+                                    or self.mask.numel() * 8 != self.y.numel()):
+            raise ValueError("batch-norm tap bitmask has the wrong size")
+        if self.relu_mode not in (0, 2, 3):
+            raise ValueError("bad relu_mode")
+
+
+def dgrad_can_tap(plan: ConvPlan) -> bool:
+    """One launch writes every input pixel (unit stride): its epilogue sees the complete gradient."""
+    return len(plan.phases) == 1 and not plan.dgrad_needs_zero
+
+
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Optional[torch.Tensor] = None,
-               addend_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+               addend_mask: Optional[torch.Tensor] = None, bn_tap: Optional[BnBackwardTap] = None) -> torch.Tensor:
     """dy [B,OH,OW,Cout] -> dx [B,IH,IW,Cin] (+ ``addend``, e.g. the gradient arriving over a
     residual connection, fused into the epilogue instead of a separate add pass; ``addend_mask`` holds
     one bit per element of ``addend`` and only set elements are added)."""
@@ -281,6 +324,10 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Option
             raise ValueError("addend bitmask size mismatch")
     elif addend_mask is not None:
         raise ValueError("addend_mask without addend")
+    if bn_tap is not None:
+        if not dgrad_can_tap(plan):
+            raise ValueError("batch-norm partials need a single-launch data gradient")
+        bn_tap.validate((B, plan.ih, plan.iw, plan.cin), plan.cin)
     if plan.dgrad_needs_zero:
         dx = torch.zeros((B, plan.ih, plan.iw, plan.cin), dtype=torch.bfloat16, device=dy.device)
     else:
@@ -289,9 +336,11 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Option
         wd = torch.empty((plan.cin, ph.T * plan.cout), dtype=torch.bfloat16, device=dy.device)
         hipk.check(L.dtfa_weight_permute(w.data_ptr(), wd.data_ptr(), ph.src_tap.data_ptr(), plan.cout, plan.T,
                                          plan.cin, ph.T, hipk.stream()), "weight_permute")
-        _launch_igemm(dy, wd, dx, ph.taps, ph.T, plan.oh, plan.ow, plan.cout, plan.ih, plan.iw, plan.cin,
-                      ph.OYn, ph.OXn, plan.sy, plan.sx, ph.oy0, ph.ox0, 1, 1, B, plan.cout_magic, addend=addend,
-                      zero_taps=plan.is_pointwise, addend_mask=addend_mask)
+        part = _launch_igemm(dy, wd, dx, ph.taps, ph.T, plan.oh, plan.ow, plan.cout, plan.ih, plan.iw, plan.cin,
+                             ph.OYn, ph.OXn, plan.sy, plan.sx, ph.oy0, ph.ox0, 1, 1, B, plan.cout_magic,
+                             addend=addend, zero_taps=plan.is_pointwise, addend_mask=addend_mask, bn_tap=bn_tap)
+        if bn_tap is not None:
+            bn_tap.partials = part
     return dx
 
 

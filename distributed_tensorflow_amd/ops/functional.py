@@ -132,15 +132,20 @@ class GradSlot:
 class Links:
     """The slots of one conv + batch-norm layer (all optional)."""
 
-    __slots__ = ("residual_grad", "residual_mask", "input_grad", "output_mask", "input_grad_out")
+    __slots__ = ("residual_grad", "residual_mask", "input_grad", "output_mask", "input_grad_out", "output_tap",
+                 "input_tap")
 
     def __init__(self, residual_grad=None, residual_mask=None, input_grad=None, output_mask=None,
-                 input_grad_out=None):
+                 input_grad_out=None, output_tap=None, input_tap=None):
         self.residual_grad = residual_grad      # park (dout, mask) of the residual for an upstream dgrad epilogue
         self.residual_mask = residual_mask      # park the mask for the layer that produced the residual
         self.input_grad = input_grad            # add this to the input gradient inside the dgrad epilogue
         self.output_mask = output_mask          # gate the incoming gradient with this mask
         self.input_grad_out = input_grad_out    # park the input gradient here instead of returning it
+        # conv.BnBackwardTap shared by a layer (output_tap) and the only consumer of its output (input_tap):
+        # the consumer's data-gradient kernel emits the layer's batch-norm backward partial sums
+        self.output_tap = output_tap
+        self.input_tap = input_tap
 
 
 _NO_LINKS = Links()
@@ -172,6 +177,11 @@ class _ConvBnActFn(Function):
         ctx.has_res = residual is not None
         ctx.params = params  # (weight_param, gamma_param, beta_param) python objects
         ctx.links = links
+        if need_grad and training and links.output_tap is not None:
+            tap = links.output_tap
+            tap.y, tap.mean, tap.invstd, tap.scale, tap.shift, tap.mask = y, mean, invstd, scale, shift, mask
+            tap.relu_mode = 0 if not relu else (3 if mask is not None else 2)
+            tap.partials = None
         if need_grad:
             keep_z = relu and not training
             ctx.save_for_backward(x, weight, y, z if keep_z else None, mask, gamma, mean, invstd, scale, shift)
@@ -194,6 +204,11 @@ class _ConvBnActFn(Function):
             gate, links.output_mask.mask = links.output_mask.mask, None
         direct = False
         dres = None
+        partials = None
+        if ctx.training and links.output_tap is not None:
+            if gate is mask:
+                partials = links.output_tap.partials
+            links.output_tap.clear()
         if ctx.training:
             # per-channel gradients go straight into the flat gradient buffer when both parameters live there
             g_mg = getattr(gparam, "main_grad", None) if (gamma is not None and ctx.needs_input_grad[2]) else None
@@ -206,7 +221,7 @@ class _ConvBnActFn(Function):
                                                  dgamma_out=g_mg if direct else None,
                                                  dbeta_out=b_mg if direct else None,
                                                  accumulate=filled if direct else False,
-                                                 scale=scale, shift=shift, mask=gate)
+                                                 scale=scale, shift=shift, mask=gate, partials=partials)
             if want_dres:
                 if mask is None:
                     dres = dz  # no activation between the sum and this layer's output
@@ -243,7 +258,13 @@ class _ConvBnActFn(Function):
             if ctx.needs_input_grad[3]:
                 gb = _deliver_small(bparam, dbeta) if bparam is not None else dbeta
         if ctx.needs_input_grad[0]:
-            gx = cv.conv_dgrad(dy, weight, plan, addend=addend, addend_mask=addend_mask)
+            # the gradient written here is complete (nothing else flows into x) when every contribution
+            # expected through the slot has arrived; then the upstream layer's reduction rides along
+            tap = links.input_tap
+            if tap is not None and not (tap.armed and cv.dgrad_can_tap(plan)
+                                        and (links.input_grad is None or addend is not None)):
+                tap = None
+            gx = cv.conv_dgrad(dy, weight, plan, addend=addend, addend_mask=addend_mask, bn_tap=tap)
             out_slot = links.input_grad_out
             if out_slot is not None and not out_slot.consumed:
                 out_slot.grad, gx = gx, None  # a sibling consumer of x adds it in its own dgrad epilogue

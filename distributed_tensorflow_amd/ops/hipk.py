@@ -32,6 +32,8 @@ class ConvArgs(C.Structure):
         ("isy", c_int), ("isx", c_int),
         ("T", c_int), ("M", c_int), ("K", c_int),
         ("cin_magic", C.c_uint), ("relu", c_int), ("dense_out", c_int), ("pointwise", c_int),
+        ("bn_y", c_void), ("bn_mean", c_void), ("bn_invstd", c_void), ("bn_scale", c_void), ("bn_shift", c_void),
+        ("bn_mask", c_void), ("bn_relu", c_int),
     ]
 
 

@@ -118,8 +118,11 @@ def bn_apply(y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bo
 
 
 def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, dgamma_out=None, dbeta_out=None,
-                accumulate=False, scale=None, shift=None, mask=None):
+                accumulate=False, scale=None, shift=None, mask=None, partials=None):
     """Returns (dy, dres or None, dgamma, dbeta).
+
+    ``partials`` ([R,2,C] sums of g and g*xhat, e.g. emitted by the data-gradient kernel that produced
+    ``dz``) replaces the reduction pass over ``dz`` / ``y``.
 
     ``mask`` (uint8, one bit per element) gates ``dz`` -- the stored sign of a ReLU output, this layer's
     own or that of the activation this layer's output was added into -- and takes precedence over
@@ -150,13 +153,18 @@ def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, d
             mode = 2
     M, Cc = _as2d(y)
     L = hipk.lib()
-    rows = L.dtfa_col_partials_rows(M, Cc)
-    part = torch.empty((rows, 2, Cc), dtype=F32, device=y.device)
     zp = hipk.ptr(zout) if mode == 1 else (mask.data_ptr() if mode == 3 else None)
     sp = scale.data_ptr() if mode == 2 else None
     hp = shift.data_ptr() if mode == 2 else None
-    hipk.check(L.dtfa_bn_bwd_partials(dz.data_ptr(), y.data_ptr(), zp, mean.data_ptr(), invstd.data_ptr(), sp, hp,
-                                      part.data_ptr(), M, Cc, mode, hipk.stream()), "bn_bwd_partials")
+    if partials is not None:
+        if partials.dim() != 3 or partials.shape[1] != 2 or partials.shape[2] != Cc or partials.dtype != F32:
+            raise ValueError("bad batch-norm backward partials")
+        part = partials
+    else:
+        rows = L.dtfa_col_partials_rows(M, Cc)
+        part = torch.empty((rows, 2, Cc), dtype=F32, device=y.device)
+        hipk.check(L.dtfa_bn_bwd_partials(dz.data_ptr(), y.data_ptr(), zp, mean.data_ptr(), invstd.data_ptr(), sp,
+                                          hp, part.data_ptr(), M, Cc, mode, hipk.stream()), "bn_bwd_partials")
     part = reduce_partials(part)
     coef = torch.empty((3, Cc), dtype=F32, device=y.device)
     for o in (dgamma_out, dbeta_out):

@@ -121,3 +121,38 @@ def test_dgrad_masked_addend():
     want = (base.float() + torch.where(keep, add.float(), torch.zeros_like(add, dtype=torch.float32))).bfloat16()
     # the kernel adds before rounding the data-gradient to bf16; allow one rounding step of difference
     torch.testing.assert_close(got.float(), want.float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("relu_mode", [0, 2, 3])
+@pytest.mark.parametrize("case", [(2, 14, 14, 64, 32, 1, 1, 1, 1, "VALID"), (3, 9, 11, 40, 72, 3, 3, 1, 1, "SAME")])
+def test_dgrad_emits_bn_backward_partials(case, relu_mode):
+    """A data-gradient launch can emit (sum g, sum g*xhat) of the batch-norm layer below it; the sums equal
+    those of the gradient tensor it wrote."""
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case)
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    assert cv.dgrad_can_tap(plan)
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(B, plan.oh, plan.ow, Cout, generator=g).bfloat16().cuda()
+    tap = cv.BnBackwardTap()
+    tap.y = torch.randn(B, H, W, Cin, generator=g).bfloat16().cuda()
+    tap.mean = torch.randn(Cin, generator=g).cuda() * 0.1
+    tap.invstd = (torch.rand(Cin, generator=g) + 0.5).cuda()
+    tap.scale = (torch.rand(Cin, generator=g) + 0.5).cuda()
+    tap.shift = torch.randn(Cin, generator=g).cuda() * 0.2
+    keep = torch.rand(B, H, W, Cin, generator=g).cuda() > 0.4
+    tap.mask = (keep.view(-1, 8).to(torch.uint8) << torch.arange(8, device="cuda", dtype=torch.uint8)).sum(1).to(torch.uint8)
+    tap.relu_mode = relu_mode
+    dx = cv.conv_dgrad(dy, w.bfloat16().cuda(), plan, bn_tap=tap)
+    assert torch.equal(dx, cv.conv_dgrad(dy, w.bfloat16().cuda(), plan))
+    yf, gf = tap.y.float(), dx.float()
+    if relu_mode == 2:
+        gf = torch.where(yf * tap.scale + tap.shift > 0, gf, torch.zeros_like(gf))
+    if relu_mode == 3:
+        gf = torch.where(keep, gf, torch.zeros_like(gf))
+    xhat = (yf - tap.mean) * tap.invstd
+    want1 = gf.reshape(-1, Cin).double().sum(0)
+    want2 = (gf * xhat).reshape(-1, Cin).double().sum(0)
+    got = tap.partials.double().sum(0)
+    torch.testing.assert_close(got[0], want1, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(got[1], want2, rtol=1e-3, atol=1e-2)
