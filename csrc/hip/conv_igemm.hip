@@ -34,7 +34,7 @@ struct ConvArgs {
   const float* bias;   // [Cout] or null
   const bf16* addend;  // optional tensor of the output's shape, added in the epilogue (residual gradient)
   const unsigned char* addend_mask;  // optional: one bit per element of addend, only set elements are added
-  float* stats;        // [mtiles*2][2][Cout] partial (sum, sumsq) or null
+  float* stats;        // [mtiles][2][Cout] partial (sum, sumsq) or null
   const bf16* zero;    // >= 16 bytes of zeros, 16-byte aligned
   const int* taps;     // T entries, (dy << 16) | (dx & 0xffff)
   int IH, IW, Cin;
@@ -301,6 +301,8 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs p) {
     return opixel * p.Cout + chunk_co;
   };
   char* ep = lds_tiles + wid * (WM * EP_PITCH);
+  float* xch = (float*)(lds_tiles + 4 * WM * EP_PITCH);  // [2 wave columns][WN][2] exchange area behind the row tiles
+  float st1[NT], st2[NT];
   const int colq = lane & 31;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -329,14 +331,27 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs p) {
     if (EPI == 1) {
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
-      if (khalf == 0 && co < p.Cout) {
-        size_t prow = (size_t)(tile_m * 2 + wr) * 2;
-        p.stats[prow * p.Cout + co] = s1;
-        p.stats[(prow + 1) * p.Cout + co] = s2;
+      st1[nt] = s1;
+      st2[nt] = s2;
+      // the lower wave row parks its sums; the upper one adds them after the barrier (one row per tile)
+      if (wr == 1 && khalf == 0) {
+        xch[((wc * NT + nt) * 32 + colq) * 2] = s1;
+        xch[((wc * NT + nt) * 32 + colq) * 2 + 1] = s2;
       }
     }
   }
   __syncthreads();
+  if (EPI == 1 && wr == 0 && khalf == 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = n0 + wc * WN + nt * 32 + colq;
+      if (co < p.Cout) {
+        const size_t prow = (size_t)tile_m * 2;
+        p.stats[prow * p.Cout + co] = st1[nt] + xch[((wc * NT + nt) * 32 + colq) * 2];
+        p.stats[(prow + 1) * p.Cout + co] = st2[nt] + xch[((wc * NT + nt) * 32 + colq) * 2 + 1];
+      }
+    }
+  }
 
   float bs1[8], bs2[8], bmu[8], bis[8], bsc[8], bsh[8];
   if (EPI == 3) {
@@ -422,12 +437,21 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs p) {
       }
     }
     const int co = chunk_co;
-    if (lane < CPR && co < p.Cout) {
-      size_t prow = (size_t)(tile_m * 2 + wr) * 2;
+    float* mine = xch + (wc * WN + (lane % CPR) * 8) * 2;
+    if (wr == 1 && lane < CPR) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        p.stats[prow * p.Cout + co + j] = bs1[j];
-        p.stats[(prow + 1) * p.Cout + co + j] = bs2[j];
+        mine[j * 2] = bs1[j];
+        mine[j * 2 + 1] = bs2[j];
+      }
+    }
+    __syncthreads();
+    if (wr == 0 && lane < CPR && co < p.Cout) {
+      const size_t prow = (size_t)tile_m * 2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        p.stats[prow * p.Cout + co + j] = bs1[j] + mine[j * 2];
+        p.stats[(prow + 1) * p.Cout + co + j] = bs2[j] + mine[j * 2 + 1];
       }
     }
   }
@@ -437,7 +461,7 @@ template <int BM, int BN, int BK, int EPI, int NST>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   constexpr int ROWB = BK * 2;
   constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int EP = 4 * (BM / 2) * ((BN / 2) * 2 + 16);
+  constexpr int EP = 4 * (BM / 2) * ((BN / 2) * 2 + 16) + 2 * (BN / 2) * 2 * 4;  // row tiles + statistics exchange
   size_t lds = MAX_TAPS * 4 + (size_t)((NST * STAGE > EP) ? NST * STAGE : EP);
   unsigned mtiles = (a.M + BM - 1) / BM, ntiles = (a.Cout + BN - 1) / BN;
   static bool attr_set = false;
@@ -458,8 +482,8 @@ static int launch_conv_epi(const ConvArgs& a, hipStream_t stream) {
   return launch_conv<BM, BN, BK, 0, NST>(a, stream);
 }
 
-// Number of partial-statistics rows the kernel writes for a given M and BM.
-extern "C" int dtfa_conv_stats_rows(int M, int bm) { return ((M + bm - 1) / bm) * 2; }
+// Number of partial-statistics rows the kernel writes for a given M and BM (one per row of tiles).
+extern "C" int dtfa_conv_stats_rows(int M, int bm) { return (M + bm - 1) / bm; }
 
 extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int nst, hipStream_t stream) {
   if (a->Cin % 8 != 0 || a->Cout % 8 != 0 || a->T > MAX_TAPS || a->T < 1) return -1;
