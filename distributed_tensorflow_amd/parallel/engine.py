@@ -85,6 +85,10 @@ class DataParallelEngine:
                 {g.name: torch.zeros_like(g.grad) for g in self.flat.groups} for _ in range(self.staleness + 1)
             ]
             self._ring_handles: List[List] = [[] for _ in range(self.staleness + 1)]
+            # version counter of every ring slot: the step whose gradient it holds.  DTFA_DEBUG_STALENESS=1
+            # asserts at every apply that the gradient is exactly ``staleness`` steps old.
+            self._ring_version: List[int] = [-1] * (self.staleness + 1)
+            self._debug_staleness = os.environ.get("DTFA_DEBUG_STALENESS") == "1"
         # buckets up to ``p2p_max_bytes`` skip RCCL and use the one-shot xGMI mailbox all-reduce
         self._p2p = None
         if p2p_max_bytes > 0 and self.collective and mode == "sync_dp" \
@@ -215,8 +219,12 @@ class DataParallelEngine:
             if not self.collective:
                 for g in self.flat.groups:
                     self._ring[slot][g.name].copy_(g.grad)
+            self._ring_version[slot] = self._step
             if self._step >= s:
                 apply_slot = (self._step - s) % (s + 1)
+                if self._debug_staleness and self._ring_version[apply_slot] != self._step - s:
+                    raise AssertionError("staleness violation: applying the gradient of step %d at step %d (bound %d)"
+                                         % (self._ring_version[apply_slot], self._step, s))
                 for h in self._ring_handles[apply_slot]:
                     h.wait()
                 self._ring_handles[apply_slot] = []

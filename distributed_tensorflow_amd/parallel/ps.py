@@ -32,6 +32,7 @@ UTF-8 JSON).
 from __future__ import annotations
 
 import json
+import os
 import socket
 import struct
 import threading
@@ -88,7 +89,15 @@ class ParameterServer:
     (recognition_flower/distributed/train_dataset.py:142-145) until a SHUTDOWN
     request arrives."""
 
-    def __init__(self, host: str, port: int, ps_index: int = 0, staleness: int = -1, worker_timeout: float = 30.0):
+    def __init__(self, host: str, port: int, ps_index: int = 0, staleness: int = -1, worker_timeout: float = 30.0,
+                 debug: Optional[bool] = None):
+        # debug mode (also DTFA_DEBUG_STALENESS=1): the allowed races are asserted on version counters --
+        # a pull is never admitted beyond the staleness bound, a worker's clock advances by exactly one per
+        # applied push, and the number of applies equals the sum of the clock advances.  Violations are
+        # recorded in ``violations`` and answered with an error status instead of being served.
+        self.debug = bool(int(os.environ.get("DTFA_DEBUG_STALENESS", "0"))) if debug is None else bool(debug)
+        self.violations: List[str] = []
+        self._clock_advances = 0
         self.addr = (host, port)
         self.ps_index = ps_index
         self.staleness = staleness
@@ -128,6 +137,9 @@ class ParameterServer:
                 if m is None or clock - m <= self.staleness:
                     if m is not None:
                         self.max_lag_seen = max(self.max_lag_seen, clock - m)
+                    if self.debug and self.max_lag_seen > self.staleness:
+                        self.violations.append("pull of worker %d admitted at lag %d > %d" % (worker, clock - m,
+                                                                                            self.staleness))
                     return
                 self.lock.wait(timeout=0.05)
 
@@ -189,6 +201,16 @@ class ParameterServer:
                         if g.numel() != self.params.numel():
                             _send_msg(conn, op, worker, ST_ERROR, 0)
                             continue
+                        if self.debug:
+                            have = self.clocks.get(worker)
+                            if have is not None and int(clock) != have:
+                                self.violations.append("worker %d pushed clock %d, ps holds %d" % (worker, int(clock), have))
+                                _send_msg(conn, op, worker, ST_ERROR, 0)
+                                continue
+                            self._clock_advances += 1
+                            if self._clock_advances != self.apply_count + 1:
+                                self.violations.append("applies %d != clock advances %d" % (self.apply_count + 1,
+                                                                                         self._clock_advances))
                         self.grad.copy_(g)
                         self.optimizer.step()
                         self.apply_count += 1
@@ -232,7 +254,8 @@ class ParameterServer:
                     with self.lock:
                         meta = json.dumps({"initialized": self.initialized, "global_step": self.global_step,
                                            "clocks": {str(k): v for k, v in self.clocks.items()},
-                                           "max_lag_seen": self.max_lag_seen, "staleness": self.staleness}).encode()
+                                           "max_lag_seen": self.max_lag_seen, "staleness": self.staleness,
+                                           "debug": self.debug, "violations": list(self.violations)}).encode()
                     _send_msg(conn, op, worker, ST_OK, self.global_step, meta)
                 elif op == OP_BYE:
                     with self.lock:

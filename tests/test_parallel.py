@@ -135,7 +135,8 @@ def test_async_ssp_applies_gradients_exactly_s_steps_late(tmp_path):
     assert not torch.equal(s2[0]["flat"], sync[0]["flat"])
 
 
-def test_async_ssp_first_s_steps_leave_parameters_untouched():
+def test_async_ssp_first_s_steps_leave_parameters_untouched(monkeypatch):
+    monkeypatch.setenv("DTFA_DEBUG_STALENESS", "1")  # every apply asserts "exactly s steps old" on the slot versions
     model = _model()
     eng = DataParallelEngine(model, mode="async_ssp", optimizer="momentum", lr=0.05, staleness=2, bucket_mb=0.02)
     before = torch.cat([g.master.clone() for g in eng.flat.groups])

@@ -126,7 +126,7 @@ def test_variables_are_placed_round_robin_over_ps_tasks(servers):
 
 
 def test_staleness_bound_is_never_exceeded(servers):
-    (ps, addr), = servers(1, staleness=1)
+    (ps, addr), = servers(1, staleness=1, debug=True)
     fast_model, slow_model = _model(1), _model(1)
     fast = PSWorkerEngine(fast_model, [addr], 0, True, lr=1e-3)
     slow = PSWorkerEngine(slow_model, [addr], 1, False, lr=1e-3)
@@ -144,6 +144,7 @@ def test_staleness_bound_is_never_exceeded(servers):
     assert not tf.is_alive() and not ts.is_alive()
     assert ps.max_lag_seen <= 1
     assert ps.global_step == 12
+    assert ps.violations == [] and fast.status()["debug"] is True  # version-counter assertions held throughout
     # reconstruct clocks over time: the fast worker never started a step more than s ahead
     clocks = {"fast": 0, "slow": 0}
     for tag, c, _ in sorted(log, key=lambda r: r[2]):
@@ -199,4 +200,18 @@ def test_checkpoint_through_ps_contains_owner_side_adam_slots(servers, tmp_path)
     eng.pull()
     w = dict(model.named_parameters())["conv1.weight"].detach()
     np.testing.assert_allclose(data["FlowerCNN/conv1/weights"], w[..., :3].permute(1, 2, 3, 0).numpy(), rtol=0, atol=0)
+    eng.close()
+
+
+def test_debug_mode_rejects_a_push_with_a_wrong_clock(servers):
+    """Debug mode asserts on version counters: a push whose clock does not match the ps's record of that
+    worker (a lost or duplicated update) is refused and recorded."""
+    (ps, addr), = servers(1, staleness=2, debug=True)
+    model = _model(3)
+    eng = PSWorkerEngine(model, [addr], 0, True, lr=1e-3)
+    _step(model, eng, 0)
+    eng.clock -= 1  # replay the same clock: a duplicated update
+    with pytest.raises(Exception):
+        _step(model, eng, 1)
+    assert any("pushed clock" in v for v in ps.violations)
     eng.close()
