@@ -1,0 +1,287 @@
+// Batch-norm + ReLU + max-pool fused around the pooling window, NHWC bf16, C % 8 == 0.
+//
+// A convolution followed by batch-norm, ReLU and a max-pool normally writes the full-resolution
+// activation z = relu(y*scale + shift) only for the pool to read it back.  Here the pool reads the
+// convolution output y directly and applies the affine map and the ReLU on the fly, so z is never
+// stored: the forward pass reads y once (window overlap is served by the cache) and writes the pooled
+// tensor plus one winning-tap byte per output element.
+//
+// Backward needs, per full-resolution element, g = dz * (z > 0) with dz the pooled gradient routed to
+// the winning tap of every window that covers the element; both batch-norm backward passes (the
+// per-channel sums, then dy = ca*g + cb*y + cc) gather it from the pooled gradient and the tap bytes
+// instead of reading a materialised dz.
+#include "common.h"
+
+__global__ void bn_relu_maxpool_fwd_kernel(const bf16* __restrict__ y, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, bf16* __restrict__ out,
+                                           unsigned char* __restrict__ idx, PoolArgs p, int relu, size_t nvec) {
+  const int cvec = p.C >> 3;
+  // (the launcher guarantees nvec < 2^31: 32-bit index arithmetic)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)nvec; i += gridDim.x * blockDim.x) {
+    const unsigned pix = i / (unsigned)cvec;
+    const int cg = (int)(i - pix * cvec);
+    const unsigned t = pix / (unsigned)p.OW;
+    const int ox = (int)(pix - t * p.OW);
+    const int b = (int)(t / (unsigned)p.OH);
+    const int oy = (int)(t - (unsigned)b * p.OH);
+    float4 sa = *(const float4*)(scale + cg * 8), sb = *(const float4*)(scale + cg * 8 + 4);
+    float4 ha = *(const float4*)(shift + cg * 8), hb = *(const float4*)(shift + cg * 8 + 4);
+    const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+    const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+    float best[8];
+    unsigned char bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      best[j] = -INFINITY;
+      bi[j] = 255;
+    }
+    for (int ky = 0; ky < p.kh; ++ky) {
+      const int iy = oy * p.sy + ky - p.pt;
+      if ((unsigned)iy >= (unsigned)p.IH) continue;
+      for (int kx = 0; kx < p.kw; ++kx) {
+        const int ix = ox * p.sx + kx - p.pl;
+        if ((unsigned)ix >= (unsigned)p.IW) continue;
+        bf16x8 v = *(const bf16x8*)(y + (((size_t)b * p.IH + iy) * p.IW + ix) * p.C + cg * 8);
+        const unsigned char tap = (unsigned char)(ky * p.kw + kx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // the value a separate batch-norm pass would have stored (rounded to bf16), so that ties and the
+          // winning tap are exactly those of the unfused sequence
+          float f = (float)v[j] * sc[j] + sh[j];
+          if (relu) f = fmaxf(f, 0.f);
+          f = (float)(bf16)f;
+          if (f > best[j] || bi[j] == 255) {
+            best[j] = f;
+            bi[j] = tap;
+          }
+        }
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)best[j];
+    *(bf16x8*)(out + (size_t)i * 8) = o;
+    if (idx) {
+      uint2 packed;
+      packed.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((unsigned)bi[3] << 24);
+      packed.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | ((unsigned)bi[7] << 24);
+      *(uint2*)(idx + (size_t)i * 8) = packed;
+    }
+  }
+}
+
+// Pooled gradient routed to full-resolution pixel (b, iy, ix), channels cg*8 .. cg*8+7.
+__device__ __forceinline__ void gather_pool_grad(const bf16* __restrict__ dp, const unsigned char* __restrict__ idx,
+                                                 const PoolArgs& p, int b, int iy, int ix, int cg, float acc[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const int ylo = iy + p.pt - p.kh + 1;
+  const int oy0 = ylo <= 0 ? 0 : (ylo + p.sy - 1) / p.sy;
+  int oy1 = (iy + p.pt) / p.sy;
+  if (oy1 > p.OH - 1) oy1 = p.OH - 1;
+  const int xlo = ix + p.pl - p.kw + 1;
+  const int ox0 = xlo <= 0 ? 0 : (xlo + p.sx - 1) / p.sx;
+  int ox1 = (ix + p.pl) / p.sx;
+  if (ox1 > p.OW - 1) ox1 = p.OW - 1;
+  for (int oy = oy0; oy <= oy1; ++oy) {
+    const int ky = iy + p.pt - oy * p.sy;
+    for (int ox = ox0; ox <= ox1; ++ox) {
+      const int kx = ix + p.pl - ox * p.sx;
+      const unsigned tap = (unsigned)(ky * p.kw + kx);
+      const size_t o = (((size_t)b * p.OH + oy) * p.OW + ox) * p.C + cg * 8;
+      const uint2 pk = *(const uint2*)(idx + o);
+      const bf16x8 g = *(const bf16x8*)(dp + o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned w = j < 4 ? pk.x : pk.y;
+        if (((w >> (8 * (j & 3))) & 0xff) == tap) acc[j] += (float)g[j];
+      }
+    }
+  }
+}
+
+// Per-channel partial sums (sum g, sum g*xhat) over a slice of pixels.  Block = TX channel groups x TY
+// pixel lanes, grid = (channel-group blocks, pixel slices); output rows [gridDim.y][2][C].
+__global__ void bn_pool_bwd_partials_kernel(const bf16* __restrict__ dp, const unsigned char* __restrict__ idx,
+                                            const bf16* __restrict__ y, const float* __restrict__ mean,
+                                            const float* __restrict__ invstd, const float* __restrict__ scale,
+                                            const float* __restrict__ shift, float* __restrict__ out, PoolArgs p,
+                                            int relu, int TX, long long rows_per_block) {
+  extern __shared__ float red[];  // [TY][TX][16]
+  const int TY = blockDim.x / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cg = blockIdx.x * TX + tx;
+  const int cvec = p.C >> 3;
+  const long long M = (long long)p.B * p.IH * p.IW;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  if (cg < cvec) {
+    float mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mu[j] = mean[cg * 8 + j];
+      is[j] = invstd[cg * 8 + j];
+      sc[j] = scale[cg * 8 + j];
+      sh[j] = shift[cg * 8 + j];
+    }
+    long long r0l = (long long)blockIdx.y * rows_per_block, r1l = r0l + rows_per_block;
+    if (r1l > M) r1l = M;
+    const unsigned r1 = (unsigned)r1l;  // M < 2^31 (checked by the launcher)
+    constexpr int U = 2;                // pixels per iteration: their loads are all in flight together
+    for (unsigned r = (unsigned)r0l + ty; r < r1; r += TY * U) {
+      bf16x8 yy[U];
+      float g[U][8];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned rr = r + u * TY;
+        ok[u] = rr < r1;
+        const unsigned rc = ok[u] ? rr : r;
+        const unsigned t = rc / (unsigned)p.IW;
+        const int ix = (int)(rc - t * p.IW);
+        const int b = (int)(t / (unsigned)p.IH);
+        const int iy = (int)(t - (unsigned)b * p.IH);
+        yy[u] = *(const bf16x8*)(y + (size_t)rc * p.C + cg * 8);
+        gather_pool_grad(dp, idx, p, b, iy, ix, cg, g[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float yf = (float)yy[u][j];
+          float gj = g[u][j];
+          if (relu && !(yf * sc[j] + sh[j] > 0.f)) gj = 0.f;
+          s1[j] += gj;
+          s2[j] += gj * ((yf - mu[j]) * is[j]);
+        }
+      }
+    }
+  }
+  float* mine = red + ((size_t)ty * TX + tx) * 16;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mine[j] = s1[j];
+    mine[8 + j] = s2[j];
+  }
+  __syncthreads();
+  if (ty == 0 && cg < cvec) {
+    for (int t = 1; t < TY; ++t) {
+      const float* o = red + ((size_t)t * TX + tx) * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s1[j] += o[j];
+        s2[j] += o[8 + j];
+      }
+    }
+    float* dst = out + (size_t)blockIdx.y * 2 * p.C + (size_t)cg * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dst[j] = s1[j];
+      dst[p.C + j] = s2[j];
+    }
+  }
+}
+
+__global__ void bn_pool_bwd_apply_kernel(const bf16* __restrict__ dp, const unsigned char* __restrict__ idx,
+                                         const bf16* __restrict__ y, bf16* __restrict__ dy,
+                                         const float* __restrict__ ca, const float* __restrict__ cb,
+                                         const float* __restrict__ cc, const float* __restrict__ scale,
+                                         const float* __restrict__ shift, PoolArgs p, int relu, size_t nvec) {
+  const int cvec = p.C >> 3;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)nvec; i += gridDim.x * blockDim.x) {
+    const unsigned pix = i / (unsigned)cvec;
+    const int cg = (int)(i - pix * cvec);
+    const unsigned t = pix / (unsigned)p.IW;
+    const int ix = (int)(pix - t * p.IW);
+    const int b = (int)(t / (unsigned)p.IH);
+    const int iy = (int)(t - (unsigned)b * p.IH);
+    const bf16x8 yy = *(const bf16x8*)(y + (size_t)i * 8);
+    float g[8];
+    gather_pool_grad(dp, idx, p, b, iy, ix, cg, g);
+    const int c0 = cg * 8;
+    const float4 a0 = *(const float4*)(ca + c0), a1 = *(const float4*)(ca + c0 + 4);
+    const float4 b0 = *(const float4*)(cb + c0), b1 = *(const float4*)(cb + c0 + 4);
+    const float4 d0 = *(const float4*)(cc + c0), d1 = *(const float4*)(cc + c0 + 4);
+    const float4 s0 = *(const float4*)(scale + c0), s1 = *(const float4*)(scale + c0 + 4);
+    const float4 h0 = *(const float4*)(shift + c0), h1 = *(const float4*)(shift + c0 + 4);
+    const float A[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float Bc[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float Cc[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    const float S[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float H[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float yf = (float)yy[j];
+      float gj = g[j];
+      if (relu && !(yf * S[j] + H[j] > 0.f)) gj = 0.f;
+      o[j] = (bf16)(A[j] * gj + Bc[j] * yf + Cc[j]);
+    }
+    *(bf16x8*)(dy + (size_t)i * 8) = o;
+  }
+}
+
+static bool pool_args_ok(const PoolArgs* p) {
+  return p->C % 8 == 0 && p->kh * p->kw <= 254 && p->kh > 0 && p->kw > 0 && p->sy > 0 && p->sx > 0 && p->B > 0 &&
+         p->OH > 0 && p->OW > 0 && (long long)p->B * p->IH * p->IW * (p->C / 8) < (1ll << 31);
+}
+
+static unsigned grid_1d(size_t nvec) {
+  size_t b = (nvec + 255) / 256;
+  return (unsigned)(b > 16384 ? 16384 : b);
+}
+
+extern "C" int dtfa_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, void* out, void* idx,
+                                        const PoolArgs* p, int relu, hipStream_t st) {
+  if (!pool_args_ok(p)) return -1;
+  size_t nvec = (size_t)p->B * p->OH * p->OW * p->C / 8;
+  hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid_1d(nvec)), dim3(256), 0, st, (const bf16*)y, scale, shift,
+                     (bf16*)out, (unsigned char*)idx, *p, relu, nvec);
+  return (int)hipGetLastError();
+}
+
+static void partials_geometry(long long M, int C, int* TX, int* gx, int* gy, long long* rpb) {
+  int cvec = C / 8, tx = 1;
+  while (tx * 2 <= cvec && tx < 64) tx *= 2;
+  *TX = tx;
+  *gx = (cvec + tx - 1) / tx;
+  long long want = 4096 / *gx;
+  if (want < 1) want = 1;
+  long long rows = (M + want - 1) / want;
+  int ty = 256 / tx;
+  if (rows < ty * 4) rows = ty * 4;
+  *rpb = rows;
+  *gy = (int)((M + rows - 1) / rows);
+}
+
+extern "C" int dtfa_bn_pool_partials_rows(const PoolArgs* p) {
+  int TX, gx, gy;
+  long long rpb;
+  partials_geometry((long long)p->B * p->IH * p->IW, p->C, &TX, &gx, &gy, &rpb);
+  return gy;
+}
+
+extern "C" int dtfa_bn_pool_bwd_partials(const void* dp, const void* idx, const void* y, const float* mean,
+                                         const float* invstd, const float* scale, const float* shift, float* out,
+                                         const PoolArgs* p, int relu, hipStream_t st) {
+  if (!pool_args_ok(p)) return -1;
+  int TX, gx, gy;
+  long long rpb;
+  partials_geometry((long long)p->B * p->IH * p->IW, p->C, &TX, &gx, &gy, &rpb);
+  hipLaunchKernelGGL(bn_pool_bwd_partials_kernel, dim3(gx, gy), dim3(256), 256 * 16 * sizeof(float), st,
+                     (const bf16*)dp, (const unsigned char*)idx, (const bf16*)y, mean, invstd, scale, shift, out, *p,
+                     relu, TX, rpb);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dtfa_bn_pool_bwd_apply(const void* dp, const void* idx, const void* y, void* dy, const float* ca,
+                                      const float* cb, const float* cc, const float* scale, const float* shift,
+                                      const PoolArgs* p, int relu, hipStream_t st) {
+  if (!pool_args_ok(p)) return -1;
+  size_t nvec = (size_t)p->B * p->IH * p->IW * p->C / 8;
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(grid_1d(nvec)), dim3(256), 0, st, (const bf16*)dp,
+                     (const unsigned char*)idx, (const bf16*)y, (bf16*)dy, ca, cb, cc, scale, shift, *p, relu, nvec);
+  return (int)hipGetLastError();
+}

@@ -65,3 +65,11 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
 }
 
 #define HIP_CHECK_LAUNCH() (int)hipGetLastError()
+
+// Geometry of a pooling window over an NHWC tensor (shared by pool.hip and bn_pool.hip).
+struct PoolArgs {
+  int B, IH, IW, C, OH, OW;
+  int kh, kw, sy, sx, pt, pl;  // kernel, stride, pad top/left
+  int count_include_pad;
+};
+

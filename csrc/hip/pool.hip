@@ -10,11 +10,6 @@
 //  * global average pool and its backward.
 #include "common.h"
 
-struct PoolArgs {
-  int B, IH, IW, C, OH, OW;
-  int kh, kw, sy, sx, pt, pl;  // kernel, stride, pad top/left
-  int count_include_pad;
-};
 
 __global__ void maxpool_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, unsigned char* __restrict__ idx,
                                    PoolArgs p, size_t nvec) {

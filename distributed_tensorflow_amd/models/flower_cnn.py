@@ -56,12 +56,9 @@ class FlowerCNN(nn.Module):
 
     def features(self, x):
         x = self.conv1(x)
-        x = self.conv2(x)
-        x = F.max_pool(x, (3, 3), (2, 2), "SAME")
-        x = self.conv3(x)
-        x = F.max_pool(x, (3, 3), (2, 2), "SAME")
-        x = self.conv4(x)
-        x = F.max_pool(x, (3, 3), (2, 2), "SAME")
+        x = self.conv2.forward_pool(x, (3, 3), (2, 2), "SAME")
+        x = self.conv3.forward_pool(x, (3, 3), (2, 2), "SAME")
+        x = self.conv4.forward_pool(x, (3, 3), (2, 2), "SAME")
         x = self.conv5(x)
         return F.global_avg_pool(x)
 

@@ -210,17 +210,28 @@ class InceptionV3(nn.Module):
             self.AuxLogits = _AuxLogitsVars(num_classes)
             self.Logits_Conv2d_1c_1x1 = Conv2d(2048, num_classes, 1, tf_scope=r + "/Logits/Conv2d_1c_1x1")
 
-    def endpoints(self, x):
-        """Yields (name, tensor) for the main-path endpoints (shape walk / tests)."""
-        for name in ("Conv2d_1a_3x3", "Conv2d_2a_3x3", "Conv2d_2b_3x3"):
+    def endpoints(self, x, fuse_pools=False):
+        """Yields (name, tensor) for the main-path endpoints (shape walk / tests).  With ``fuse_pools`` the
+        two stem max-pools are computed together with the layer before them, whose own (un-pooled)
+        endpoint is then not produced."""
+        for name in ("Conv2d_1a_3x3", "Conv2d_2a_3x3"):
             x = getattr(self, name)(x)
             yield name, x
-        x = F.max_pool(x, (3, 3), (2, 2), "VALID")
+        if fuse_pools:
+            x = self.Conv2d_2b_3x3.forward_pool(x, (3, 3), (2, 2), "VALID")
+        else:
+            x = self.Conv2d_2b_3x3(x)
+            yield "Conv2d_2b_3x3", x
+            x = F.max_pool(x, (3, 3), (2, 2), "VALID")
         yield "MaxPool_3a_3x3", x
-        for name in ("Conv2d_3b_1x1", "Conv2d_4a_3x3"):
-            x = getattr(self, name)(x)
-            yield name, x
-        x = F.max_pool(x, (3, 3), (2, 2), "VALID")
+        x = self.Conv2d_3b_1x1(x)
+        yield "Conv2d_3b_1x1", x
+        if fuse_pools:
+            x = self.Conv2d_4a_3x3.forward_pool(x, (3, 3), (2, 2), "VALID")
+        else:
+            x = self.Conv2d_4a_3x3(x)
+            yield "Conv2d_4a_3x3", x
+            x = F.max_pool(x, (3, 3), (2, 2), "VALID")
         yield "MaxPool_5a_3x3", x
         for name in ("Mixed_5b", "Mixed_5c", "Mixed_5d", "Mixed_6a", "Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e",
                      "Mixed_7a", "Mixed_7b", "Mixed_7c"):
@@ -232,7 +243,7 @@ class InceptionV3(nn.Module):
 
     def forward(self, x):
         out = None
-        for _, out in self.endpoints(x):
+        for _, out in self.endpoints(x, fuse_pools=True):
             pass
         return out
 

@@ -61,6 +61,13 @@ class ConvBnAct(nn.Module):
             if t is not None:
                 t._keep_fp32 = True
 
+    def forward_pool(self, x, kernel=(3, 3), stride=(2, 2), padding="VALID"):
+        """This layer followed by a max-pool, fused on the device (the un-pooled activation is not stored)."""
+        return F.conv_bn_act_pool(x, self.weight, self.gamma, self.beta, self.running_mean, self.running_var,
+                                  stride=self.stride, padding=self.padding, eps=self.eps, momentum=self.momentum,
+                                  relu=self.relu, training=self.training, pool_kernel=_pair(kernel),
+                                  pool_stride=_pair(stride), pool_padding=padding)
+
     def forward(self, x, residual=None, links=None, out=None):
         return F.conv_bn_act(x, self.weight, self.gamma, self.beta, self.running_mean, self.running_var,
                              stride=self.stride, padding=self.padding, eps=self.eps, momentum=self.momentum,

@@ -81,8 +81,7 @@ class ResNet50(nn.Module):
 
     def forward(self, x):
         """x: [B, H, W, 8] -> logits [B, padded classes] (first ``num_classes`` columns are real)."""
-        x = self.stem(x)
-        x = F.max_pool(x, (3, 3), (2, 2), (1, 1, 1, 1))
+        x = self.stem.forward_pool(x, (3, 3), (2, 2), (1, 1, 1, 1))
         tap = None
         for i, block in enumerate(self.blocks):
             nxt = cv.BnBackwardTap() if (x.is_cuda and i + 1 < len(self.blocks)) else None

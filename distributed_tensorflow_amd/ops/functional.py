@@ -271,6 +271,83 @@ class _ConvBnActFn(Function):
         return gx, gw, gg, gb, dres, None, None, None, None, None, None, None, None, None
 
 
+class _ConvBnActPoolFn(Function):
+    """conv -> batch-norm -> ReLU -> max-pool; the full-resolution activation is never stored."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, plan, run_mean, run_var, eps, momentum, relu, training, params, pool):
+        need_grad = any(ctx.needs_input_grad)
+        y, part = cv.conv_fwd(x, weight, plan, want_stats=training)
+        M = y.numel() // plan.cout
+        if training:
+            mean, invstd, scale, shift = K.bn_finalize(part, M, eps, gamma, beta, run_mean, run_var, momentum)
+        else:
+            scale, shift = K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
+            mean = invstd = None
+        k, stride, pads = pool
+        out, idx = K.bn_relu_maxpool_fwd(y, scale, shift, relu, k, stride, pads, want_index=need_grad)
+        ctx.plan, ctx.relu, ctx.training, ctx.params, ctx.pool = plan, relu, training, params, pool
+        if need_grad:
+            ctx.save_for_backward(x, weight, y, idx, gamma, mean, invstd, scale, shift)
+        return out
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, weight, y, idx, gamma, mean, invstd, scale, shift = ctx.saved_tensors
+        plan = ctx.plan
+        wparam, gparam, bparam = ctx.params
+        k, stride, pads = ctx.pool
+        dp = dp.contiguous()
+        if not ctx.training:
+            raise NotImplementedError("backward through a frozen-statistics conv+pool block")
+        g_mg = getattr(gparam, "main_grad", None) if (gamma is not None and ctx.needs_input_grad[2]) else None
+        b_mg = getattr(bparam, "main_grad", None) if ctx.needs_input_grad[3] else None
+        filled = getattr(bparam, "_grad_filled", False)
+        direct = (b_mg is not None and b_mg.dtype == torch.float32
+                  and (gamma is None or (g_mg is not None and g_mg.dtype == torch.float32
+                                         and getattr(gparam, "_grad_filled", False) == filled)))
+        dy, dgamma, dbeta = K.bn_pool_backward(dp, idx, y, mean, invstd, gamma, scale, shift, ctx.relu, k, stride, pads,
+                                               dgamma_out=g_mg if direct else None, dbeta_out=b_mg if direct else None,
+                                               accumulate=filled if direct else False)
+        gx = gw = gg = gb = None
+        if ctx.needs_input_grad[1]:
+            gw = _deliver_wgrad(wparam if wparam is not None else weight, x, dy, plan)
+        if direct:
+            if gamma is not None:
+                _notify(gparam)
+            _notify(bparam)
+        else:
+            if gamma is not None and ctx.needs_input_grad[2]:
+                gg = _deliver_small(gparam if gparam is not None else gamma, dgamma)
+            if ctx.needs_input_grad[3]:
+                gb = _deliver_small(bparam, dbeta) if bparam is not None else dbeta
+        if ctx.needs_input_grad[0]:
+            gx = cv.conv_dgrad(dy, weight, plan)
+        return gx, gw, gg, gb, None, None, None, None, None, None, None, None, None
+
+
+def conv_bn_act_pool(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, eps, momentum, relu, training,
+                     pool_kernel=(3, 3), pool_stride=(2, 2), pool_padding="VALID"):
+    """``maxpool(act(bn(conv(x, weight))))``.  On the device the pool reads the convolution output and
+    applies the normalisation and the activation on the fly (csrc/hip/bn_pool.hip)."""
+    if not _use_hip(x):
+        z = conv_bn_act(x, weight, gamma, beta, run_mean, run_var, stride=stride, padding=padding, eps=eps,
+                        momentum=momentum, relu=relu, training=training)
+        return max_pool(z, pool_kernel, pool_stride, pool_padding)
+    kh, kw = weight.shape[1], weight.shape[2]
+    sy, sx = stride
+    pads = cv.resolve_pads(padding, x.shape[1], x.shape[2], kh, kw, sy, sx)
+    plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], weight.shape[0], kh, kw, sy, sx, pads, x.device)
+    ppads = cv.resolve_pads(pool_padding, plan.oh, plan.ow, pool_kernel[0], pool_kernel[1], pool_stride[0],
+                            pool_stride[1])
+    if _needs_grad(x, weight, gamma, beta) and not training:
+        z = conv_bn_act(x, weight, gamma, beta, run_mean, run_var, stride=stride, padding=padding, eps=eps,
+                        momentum=momentum, relu=relu, training=training)
+        return max_pool(z, pool_kernel, pool_stride, pool_padding)
+    return _ConvBnActPoolFn.apply(x, weight, gamma, beta, plan, run_mean, run_var, eps, momentum, relu, training,
+                                  (weight, gamma, beta), (tuple(pool_kernel), tuple(pool_stride), tuple(ppads)))
+
+
 def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, eps, momentum, relu, training,
                 residual=None, links=None, out=None):
     """``act(bn(conv(x, weight)) + residual)``; batch statistics when ``training``.

@@ -263,6 +263,67 @@ def maxpool_bwd(dy, idx, x_shape, k, stride, pads):
     return dx
 
 
+def bn_relu_maxpool_fwd(y, scale, shift, relu: bool, k, stride, pads, want_index=True):
+    """``maxpool(act(y*scale + shift))`` without storing the full-resolution activation.
+    Returns (pooled, winning-tap bytes or None)."""
+    hipk.require(y, BF16, "y")
+    Cc = y.shape[3]
+    if scale.numel() != Cc or shift.numel() != Cc or scale.dtype != F32 or shift.dtype != F32:
+        raise ValueError("scale/shift size mismatch")
+    oh, ow = pool_out_shape(y.shape, k, stride, pads)
+    p = _pool_args(y.shape, k, stride, pads, oh, ow)
+    out = torch.empty((y.shape[0], oh, ow, Cc), dtype=BF16, device=y.device)
+    idx = torch.empty(out.shape, dtype=torch.uint8, device=y.device) if want_index else None
+    hipk.check(hipk.lib().dtfa_bn_relu_maxpool_fwd(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+                                                   hipk.ptr(idx), C.byref(p), 1 if relu else 0, hipk.stream()),
+               "bn_relu_maxpool_fwd")
+    return out, idx
+
+
+def bn_pool_backward(dp, idx, y, mean, invstd, gamma, scale, shift, relu: bool, k, stride, pads,
+                     dgamma_out=None, dbeta_out=None, accumulate=False):
+    """Backward of ``maxpool(act(bn(y)))`` given the pooled gradient ``dp`` and the winning-tap bytes:
+    returns (dy, dgamma, dbeta).  The full-resolution gradient of the pool is gathered on the fly in both
+    passes and never stored."""
+    hipk.require(dp, BF16, "dp")
+    hipk.require(y, BF16, "y")
+    hipk.require(idx, torch.uint8, "idx")
+    oh, ow = pool_out_shape(y.shape, k, stride, pads)
+    Cc = y.shape[3]
+    if tuple(dp.shape) != (y.shape[0], oh, ow, Cc) or idx.shape != dp.shape:
+        raise ValueError("bn_pool_backward shapes")
+    for t in (mean, invstd, scale, shift):
+        if t.dtype != F32 or t.numel() != Cc:
+            raise ValueError("bn_pool_backward statistics size")
+    p = _pool_args(y.shape, k, stride, pads, oh, ow)
+    L = hipk.lib()
+    M = y.numel() // Cc
+    rows = L.dtfa_bn_pool_partials_rows(C.byref(p))
+    part = torch.empty((rows, 2, Cc), dtype=F32, device=y.device)
+    hipk.check(L.dtfa_bn_pool_bwd_partials(dp.data_ptr(), idx.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                           invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), part.data_ptr(),
+                                           C.byref(p), 1 if relu else 0, hipk.stream()), "bn_pool_bwd_partials")
+    part = reduce_partials(part)
+    coef = torch.empty((3, Cc), dtype=F32, device=y.device)
+    for o in (dgamma_out, dbeta_out):
+        if o is not None and (o.dtype != F32 or o.numel() != Cc or not o.is_contiguous()):
+            raise ValueError("bad per-channel gradient output buffer")
+    acc = 1 if (accumulate and dbeta_out is not None) else 0
+    dgamma = dgamma_out if dgamma_out is not None else torch.zeros(Cc, dtype=F32, device=y.device) if acc \
+        else torch.empty(Cc, dtype=F32, device=y.device)
+    dbeta = dbeta_out if dbeta_out is not None else torch.empty(Cc, dtype=F32, device=y.device)
+    hipk.check(L.dtfa_bn_bwd_finalize(part.data_ptr(), part.shape[0], Cc, float(M), hipk.ptr(gamma),
+                                      mean.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                      coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), acc,
+                                      hipk.stream()), "bn_bwd_finalize")
+    dy = torch.empty_like(y)
+    hipk.check(L.dtfa_bn_pool_bwd_apply(dp.data_ptr(), idx.data_ptr(), y.data_ptr(), dy.data_ptr(),
+                                        coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), scale.data_ptr(),
+                                        shift.data_ptr(), C.byref(p), 1 if relu else 0, hipk.stream()),
+               "bn_pool_bwd_apply")
+    return dy, dgamma, dbeta
+
+
 def avgpool_fwd(x, k, stride, pads, include_pad=False):
     hipk.require(x, BF16, "x")
     oh, ow = pool_out_shape(x.shape, k, stride, pads)

@@ -193,3 +193,30 @@ def test_dropout_deterministic_and_unbiased():
     assert abs(a.float().mean().item() - 1.0) < 0.04
     d = K.dropout(x, 0.8, seed=5)
     assert abs((d != 0).float().mean().item() - 0.2) < 0.02
+
+
+@pytest.mark.parametrize("shape,k,stride,pads,relu", [
+    ((2, 17, 19, 24), (3, 3), (2, 2), (1, 1, 1, 1), True),
+    ((3, 16, 16, 64), (3, 3), (2, 2), (0, 1, 0, 1), True),
+    ((2, 9, 11, 8), (2, 2), (2, 2), (0, 0, 0, 0), False),
+])
+def test_bn_relu_maxpool_fused_matches_unfused(shape, k, stride, pads, relu):
+    """The fused batch-norm + ReLU + max-pool pair (forward and backward) is bit-identical to the separate
+    batch-norm and pooling kernels."""
+    C = shape[-1]
+    y = _rand(*shape, seed=21).cuda()
+    gamma, beta = (torch.rand(C) + 0.5).cuda(), (torch.randn(C) * 0.3).cuda()
+    part = K.bn_stats_partials(y)
+    mean, invstd, sc, sh = K.bn_finalize(part, y.numel() // C, 1e-5, gamma, beta, None, None, 0.1)
+    z = K.bn_apply(y, sc, sh, relu)
+    p_ref, idx_ref = K.maxpool_fwd(z, k, stride, pads)
+    p_fused, idx = K.bn_relu_maxpool_fwd(y, sc, sh, relu, k, stride, pads)
+    assert torch.equal(p_ref, p_fused) and torch.equal(idx_ref, idx)
+    dp = _rand(*p_ref.shape, seed=22).cuda()
+    dz = K.maxpool_bwd(dp, idx_ref, tuple(z.shape), k, stride, pads)
+    dy_ref, _, dg_ref, db_ref = K.bn_backward(dz, y, None, mean, invstd, gamma, relu, False, scale=sc, shift=sh)
+    dy, dg, db = K.bn_pool_backward(dp, idx, y, mean, invstd, gamma, sc, sh, relu, k, stride, pads)
+    # dz is rounded to bf16 in the unfused path before it enters the sums; the fused path keeps fp32
+    torch.testing.assert_close(dg, dg_ref, rtol=2e-2, atol=2e-2 * dg_ref.abs().max().item())
+    torch.testing.assert_close(db, db_ref, rtol=2e-2, atol=2e-2 * db_ref.abs().max().item())
+    assert (dy.float() - dy_ref.float()).abs().max().item() <= 3e-2 * dy_ref.float().abs().max().item()
