@@ -26,6 +26,24 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same copy issued from inline assembly.  The compiler does not see it as an LDS write, so it inserts
+// no conservative "s_waitcnt vmcnt(0)" in front of LDS reads it cannot disambiguate from the copy (the
+// transposed ds_read_b64_tr_b16 reads are such reads); every wait for these copies is then the caller's
+// explicit counted s_waitcnt vmcnt(N) followed by a barrier.
+__device__ __forceinline__ void glds16_untracked(const void* gsrc, void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = (unsigned)(uintptr_t)(LDS_AS char*)lds_wave_base;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(dst)
+      : "memory");
+}
+
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // Wait until at most N vector-memory operations (LDS-DMA loads included) are outstanding.
 template <int N>

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int KS = BKP / 16;
   constexpr int STAGE = BKP * (RBA + RBB);
+  constexpr int NST = BKP == 32 ? 3 : 2;            // LDS stages
   static_assert(NA >= 1 && NB >= 1, "tile too small");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -123,14 +124,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     for (int i = 0; i < NA; ++i) {
       int m = kt * BKP + (i * 4 + wid) * RPIA + a_row;
       const bf16* src = (a_ok && m < p.M) ? p.dy + (size_t)m * p.Cout + a_co : p.zero;
-      glds16(src, sa + (i * 4 + wid) * 1024);
+      glds16_untracked(src, sa + (i * 4 + wid) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       int iy = boy[i] * p.isy + b_dy, ix = box[i] * p.isx + b_dx;
       bool ok = b_kok && bm[i] < p.M && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
       const bf16* src = ok ? p.x + ((size_t)(bpix[i] + iy * p.IW + ix) * p.Cin + b_ci) : p.zero;
-      glds16(src, sb + (i * 4 + wid) * 1024);
+      glds16_untracked(src, sb + (i * 4 + wid) * 1024);
       // advance this row by one k-tile (BKP pixels)
       bm[i] += BKP;
       box[i] += p.step_x;
@@ -160,51 +161,76 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
 
+  // NST LDS stages: while k-tile kt is multiplied, the tiles up to kt+NST-1 are in flight (counted vmcnt,
+  // raw barrier: __syncthreads() would drain every outstanding LDS-DMA load).  Fragments of k-step ks+1 are
+  // read while the MFMAs of ks run; the first fragments of tile kt+1 are read behind the barrier, ahead of
+  // the last MFMAs of tile kt.
+  constexpr int LPS = NA + NB;
+  static_assert(KS % 2 == 0, "fragment double-buffering assumes an even number of k-steps per tile");
+  s16x8 af[2][MT], bfr[2][NT];
+  auto load_frags = [&](int buf, int ks, int dst) {
+    const char* sa = lds_tiles + buf * STAGE;
+    const char* sb = sa + BKP * RBA;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int krow = ks * 16 + tr_k + 4 * r;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        int ch = (acol[mt] >> 3) ^ wswz<RBA>(krow);
+        s16x4 v = lds_tr_read(sa + krow * RBA + ch * 16 + (acol[mt] & 7) * 2);
+        af[dst][mt][4 * r + 0] = v[0]; af[dst][mt][4 * r + 1] = v[1];
+        af[dst][mt][4 * r + 2] = v[2]; af[dst][mt][4 * r + 3] = v[3];
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        int ch = (bcol[nt] >> 3) ^ wswz<RBB>(krow);
+        s16x4 v = lds_tr_read(sb + krow * RBB + ch * 16 + (bcol[nt] & 7) * 2);
+        bfr[dst][nt][4 * r + 0] = v[0]; bfr[dst][nt][4 * r + 1] = v[1];
+        bfr[dst][nt][4 * r + 2] = v[2]; bfr[dst][nt][4 * r + 3] = v[3];
+      }
+    }
+  };
+  auto mfma_step = [&](int src) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, af[src][mt]), __builtin_bit_cast(bf16x8, bfr[src][nt]), acc[mt][nt], 0, 0, 0);
+  };
+
   if (kt_begin < kt_end) {
     stage(kt_begin, 0);
-    wait_vmcnt0();
+    if (NST == 3 && kt_begin + 1 < kt_end) {
+      stage(kt_begin + 1, 1);
+      wait_vmcnt<LPS>();
+    } else {
+      wait_vmcnt<0>();
+    }
     __syncthreads();
+    load_frags(0, 0, 0);
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-      if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
-      const char* sa = lds_tiles + cur * STAGE;
-      const char* sb = sa + BKP * RBA;
-      auto load_frags = [&](int ks, s16x8* af, s16x8* bfr) {
+      const int nxt = cur == NST - 1 ? 0 : cur + 1;
+      // the slot requested here held tile kt-1, which every wave finished reading before the last barrier
+      if (kt + NST - 1 < kt_end) stage(kt + NST - 1, NST == 2 ? nxt : (nxt == 2 ? 0 : nxt + 1));
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int krow = ks * 16 + tr_k + 4 * r;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            int ch = (acol[mt] >> 3) ^ wswz<RBA>(krow);
-            s16x4 v = lds_tr_read(sa + krow * RBA + ch * 16 + (acol[mt] & 7) * 2);
-            af[mt][4 * r + 0] = v[0]; af[mt][4 * r + 1] = v[1];
-            af[mt][4 * r + 2] = v[2]; af[mt][4 * r + 3] = v[3];
-          }
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            int ch = (bcol[nt] >> 3) ^ wswz<RBB>(krow);
-            s16x4 v = lds_tr_read(sb + krow * RBB + ch * 16 + (bcol[nt] & 7) * 2);
-            bfr[nt][4 * r + 0] = v[0]; bfr[nt][4 * r + 1] = v[1];
-            bfr[nt][4 * r + 2] = v[2]; bfr[nt][4 * r + 3] = v[3];
-          }
-        }
-      };
-      s16x8 af[2][MT], bfr[2][NT];
-      load_frags(0, af[0], bfr[0]);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int c = ks & 1;
-        if (ks + 1 < KS) load_frags(ks + 1, af[c ^ 1], bfr[c ^ 1]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, af[c][mt]), __builtin_bit_cast(bf16x8, bfr[c][nt]), acc[mt][nt], 0, 0, 0);
+      for (int ks = 0; ks + 1 < KS; ++ks) {
+        load_frags(cur, ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs
+        mfma_step(ks & 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      wait_vmcnt0();
-      __syncthreads();
-      cur ^= 1;
+      if (kt + 1 < kt_end) {
+        if (NST == 3 && kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(nxt, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mfma_step((KS - 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
   }
 
@@ -268,7 +294,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 
 template <int BMW, int BNW, int BKP>
 static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t stream) {
-  size_t lds = MAX_TAPS * 4 + 2 * (size_t)BKP * (BMW * 2 + BNW * 2);
+  size_t lds = MAX_TAPS * 4 + (BKP == 32 ? 3 : 2) * (size_t)BKP * (BMW * 2 + BNW * 2);
   unsigned mt = (a.Cout + BMW - 1) / BMW, nt = (a.K + BNW - 1) / BNW;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {

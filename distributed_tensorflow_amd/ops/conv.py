@@ -183,7 +183,7 @@ def pick_fwd_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
 def pick_wgrad_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
     forced = _env_tile("DTFA_WGRAD_TILE")
     bmw = 128 if cout > 64 else 64
-    bnw = 128 if K > 64 else 64
+    bnw = 128 if (K > 64 and cout > 64) else 64  # narrow outputs: 64x64 tiles won every such shape in the sweep
     bkp = 32
     if forced:
         bmw, bnw, bkp = forced[:3]
