@@ -156,6 +156,46 @@ class SummarySaverHook(Hook):
             self.writer = None
 
 
+class ProfilerHook(Hook):
+    """Trace a window of steps with ``torch.profiler`` (CPU + device activities) and write a Chrome trace;
+    every step is also bracketed by a marker range (``roctx`` on ROCm) so that ``rocprofv3 --marker-trace``
+    shows step boundaries.  The reference has no tracing at all (its only structural dump is the graph it
+    hands to ``FileWriter``, recognition_flower/single/flower_train.py:174)."""
+
+    def __init__(self, output_dir: str, start_step: int = 5, num_steps: int = 3):
+        self.output_dir, self.start, self.n = output_dir, max(1, start_step), max(1, num_steps)
+        self.prof = None
+        self.trace_path: Optional[str] = None
+
+    def before_step(self, session, step: int) -> None:
+        if step == self.start and self.prof is None:
+            import torch.profiler as tp
+
+            acts = [tp.ProfilerActivity.CPU] + ([tp.ProfilerActivity.CUDA] if torch.cuda.is_available() else [])
+            self.prof = tp.profile(activities=acts)
+            self.prof.__enter__()
+        if torch.cuda.is_available():
+            torch.cuda.nvtx.range_push("train_step_%d" % step)
+
+    def after_step(self, session, r):
+        import os
+
+        if torch.cuda.is_available():
+            torch.cuda.nvtx.range_pop()
+        if self.prof is not None and r.global_step >= self.start + self.n - 1:
+            self.prof.__exit__(None, None, None)
+            os.makedirs(self.output_dir, exist_ok=True)
+            self.trace_path = os.path.join(self.output_dir, "trace_steps_%d_%d.json" % (self.start, r.global_step))
+            self.prof.export_chrome_trace(self.trace_path)
+            self.prof = None
+            self.start = 1 << 62  # one window per run
+
+    def end(self, session):
+        if self.prof is not None:
+            self.prof.__exit__(None, None, None)
+            self.prof = None
+
+
 class TrainingSession:
     """Runs training steps of ``model`` through ``engine`` and dispatches hooks.
 
@@ -243,6 +283,10 @@ class TrainingSession:
 
     def run_step(self, images, labels) -> StepResult:
         self._begin()
+        for h in self.hooks:
+            before = getattr(h, "before_step", None)
+            if before is not None:
+                before(self, self.global_step + 1)
         t0 = time.perf_counter()
         self.model.train()
         lr = self.engine.optimizer.current_lr()

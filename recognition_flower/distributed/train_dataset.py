@@ -62,6 +62,7 @@ flags.DEFINE_boolean("synthetic", False, "Use synthetic input instead of the TFR
 flags.DEFINE_boolean("legacy_bgr_input", False, "Feed BGR [0,255] pixels like the reference's reader.")
 flags.DEFINE_string("device", "auto", "cuda | cpu | auto")
 flags.DEFINE_integer("p2p_small_kb", 0, "sync_dp on GPUs: gradient buckets up to this size use the one-shot xGMI mailbox all-reduce instead of RCCL (0 = off)")
+flags.DEFINE_string("profile_dir", "", "Write a torch.profiler Chrome trace of a few steps here (empty = off).")
 flags.DEFINE_boolean("hip_graph", False, "collective modes on GPU: replay the step (including its collectives) from a HIP graph")
 flags.DEFINE_string("fault_inject", "", "Testing hook: 'exit_at_step:N' makes this worker die abruptly at global step N.")
 flags.DEFINE_boolean("shutdown_ps", True, "The chief stops the ps tasks when it finishes (the reference's ps never exits).")
@@ -183,6 +184,10 @@ def run_worker(spec):
              SummarySaverHook(FLAGS.save_steps, os.path.join(FLAGS.summaries_dir + str(FLAGS.model_version), "train")),
              ThroughputMeter(world_size=world),
              LoggingHook(2, worker_index=task_index)]
+    if FLAGS.profile_dir:
+        from distributed_tensorflow_amd.train.session import ProfilerHook
+
+        hooks.append(ProfilerHook(os.path.join(FLAGS.profile_dir, "task%d" % task_index)))
     head_l2 = getattr(getattr(model, "head", None), "act_l2", 0.0)
     # the reference scales the activity regulariser by 0.01 in this script (train_dataset.py:159-160)
     sess = TrainingSession(model, engine, num_classes=n_classes, hooks=hooks, is_chief=is_chief, reg_weight=0.01,

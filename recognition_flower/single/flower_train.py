@@ -51,6 +51,7 @@ flags.DEFINE_string("device", "auto", "cuda | cpu | auto")
 flags.DEFINE_integer("max_steps", 0, "Stop after this many steps (0 = n_epochs * iterations per epoch).")
 flags.DEFINE_integer("seed", 42, "Random seed.")
 flags.DEFINE_string("checkpoint_dir", "", "Also write a training checkpoint here at the end (optional).")
+flags.DEFINE_string("profile_dir", "", "Write a torch.profiler Chrome trace of a few steps here (empty = off).")
 flags.DEFINE_boolean("hip_graph", True, "replay the training step from a HIP graph (GPU only; steps of a different batch size run eagerly)")
 flags.DEFINE_boolean("export", True, "Export the servable at the end.")
 
@@ -100,6 +101,10 @@ def main(argv):
     meter = ThroughputMeter()
     hooks = [SummarySaverHook(1, os.path.join(FLAGS.summaries_dir + str(FLAGS.model_version), "train")), meter,
              LoggingHook(1)]
+    if FLAGS.profile_dir:
+        from distributed_tensorflow_amd.train.session import ProfilerHook
+
+        hooks.append(ProfilerHook(FLAGS.profile_dir))
     head_l2 = getattr(getattr(model, "head", None), "act_l2", 0.0)
     sess = TrainingSession(model, engine, num_classes=len(flower_classes), hooks=hooks, global_step=global_step,
                            logits_act_l2=head_l2, hip_graph=FLAGS.hip_graph and device.type == "cuda")

@@ -33,8 +33,9 @@ def test_single_trainer_trains_exports_and_serves(tmp_path):
     out = tmp_path / "out"
     r = _run(["flower_train.py", "--dataset_path=" + data, "--image_size=32", "--n_epochs=6", "--batch_size=8",
               "--learning_rate=0.01", "--output_dir=%s/models" % out, "--summaries_dir=%s/events/" % out,
-              "--checkpoint_dir=%s/ckpt" % out, "--model_version=3"], SINGLE)
+              "--checkpoint_dir=%s/ckpt" % out, "--model_version=3", "--profile_dir=%s/prof" % out], SINGLE)
     assert r.returncode == 0, r.stdout[-3000:]
+    assert glob.glob(str(out / "prof" / "trace_steps_*.json"))  # torch.profiler window
     losses = [float(m) for m in re.findall(r"loss (\d+\.\d+)", r.stdout)]
     assert len(losses) >= 12 and np.mean(losses[-3:]) < np.mean(losses[:3])  # loss decreases
     assert "Done exporting!" in r.stdout
