@@ -100,43 +100,87 @@ def _executor(threads: int) -> ThreadPoolExecutor:
     return _pool
 
 
+_staging = {}
+
+
+def _coef_staging(device: torch.device, n_int16: int) -> torch.Tensor:
+    """Pinned int16 host buffers (two per device, used alternately) that the entropy decoders fill in
+    place: one asynchronous upload per batch, no host-side concatenation."""
+    key = str(device)
+    ring = _staging.setdefault(key, {"bufs": [None, None], "events": [None, None], "turn": 0})
+    k = ring["turn"]
+    ring["turn"] = k ^ 1
+    if ring["events"][k] is not None:
+        ring["events"][k].synchronize()  # the upload that last used this buffer has finished
+    buf = ring["bufs"][k]
+    if buf is None or buf.numel() < n_int16:
+        buf = torch.empty(max(n_int16, 1 << 20), dtype=torch.int16)
+        if device.type == "cuda":
+            buf = buf.pin_memory()
+        ring["bufs"][k] = buf
+    return buf, ring, k
+
+
 def decode_batch_to_device(jpegs: Sequence[bytes], device, threads: int = 8):
     """Decode a batch of JPEG byte strings.
 
     Returns ``(packed uint8 device buffer of RGB HWC images, shapes, offsets)``;
     offsets are 16-byte aligned so the buffer can feed ``resize_on_device``
-    directly.  Entropy decoding runs on ``threads`` host threads (the C++ call
-    releases the GIL); files the native decoder rejects are decoded with PIL and
-    uploaded as pixels.
+    directly.  Headers are parsed first so that every image's coefficients have a
+    fixed place in one pinned staging buffer; entropy decoding then runs on
+    ``threads`` host threads straight into that buffer (the C++ call releases the
+    GIL) and the batch goes to the device in one asynchronous copy.  Files the
+    native decoder rejects are decoded with PIL and uploaded as pixels.
     """
     from ..ops import hipk
 
     device = torch.device(device)
-    results = list(_executor(threads).map(entropy_decode, jpegs))
+    Lh = hostlib.lib()
     n = len(jpegs)
+    infos: List[Optional[hostlib.JpegInfo]] = []
+    coef_pos = 0
+    coef_off = [0] * n
+    for i, data in enumerate(jpegs):
+        info = hostlib.JpegInfo()
+        if Lh.dtfa_jpeg_parse_header(data, len(data), C.byref(info)) != 0 or info.ncomp not in (1, 3):
+            infos.append(None)
+            continue
+        infos.append(info)
+        coef_off[i] = coef_pos
+        coef_pos += (info.total_coefs + 7) // 8 * 8
+    staging, ring, turn = _coef_staging(device, coef_pos)
+    base = staging.data_ptr()
+
+    def decode_one(i):
+        info = infos[i]
+        if info is None:
+            return False
+        return Lh.dtfa_jpeg_decode_coefs(jpegs[i], len(jpegs[i]), C.byref(info), base + 2 * coef_off[i],
+                                         info.total_coefs) == 0
+
+    ok = list(_executor(threads).map(decode_one, range(n)))
     shapes: List[Tuple[int, int, int]] = [None] * n  # type: ignore[list-item]
     rgb_off: List[int] = [0] * n
     pos = 0
     fallback = {}
-    for i, r in enumerate(results):
-        if r is None:
+    for i in range(n):
+        if not ok[i]:
             img = decode_pil(jpegs[i])
             fallback[i] = img
             h, w = img.shape[:2]
         else:
-            h, w = r[0].height, r[0].width
+            h, w = infos[i].height, infos[i].width
         shapes[i] = (h, w, 3)
         rgb_off[i] = pos
         pos += (h * w * 3 + 15) // 16 * 16
     out = torch.empty(max(pos, 16), dtype=torch.uint8, device=device)
-    native = [i for i in range(n) if results[i] is not None]
+    native = [i for i in range(n) if ok[i]]
     if native:
         descs = (_JpegDesc * len(native))()
-        coef_pos = plane_pos = 0
+        plane_pos = 0
         max_blocks = max_pixels = 0
-        chunks = []
         for k, i in enumerate(native):
-            info, coefs = results[i]
+            info = infos[i]
             d = descs[k]
             d.width, d.height, d.ncomp = info.width, info.height, info.ncomp
             d.hmax, d.vmax = info.hmax, info.vmax
@@ -145,17 +189,18 @@ def decode_batch_to_device(jpegs: Sequence[bytes], device, threads: int = 8):
             for c in range(info.ncomp):
                 d.hs[c], d.vs[c] = info.hs[c], info.vs[c]
                 d.blocks_w[c], d.blocks_h[c] = info.blocks_w[c], info.blocks_h[c]
-                d.coef_offset[c] = coef_pos + info.coef_offset[c]
+                d.coef_offset[c] = coef_off[i] + info.coef_offset[c]
                 d.plane_offset[c] = plane_pos
                 plane_pos += info.blocks_w[c] * info.blocks_h[c] * 64
                 nblocks += info.blocks_w[c] * info.blocks_h[c]
-                for q in range(64):
-                    d.qt[c][q] = info.qt[c][q]
-            coef_pos += info.total_coefs
-            chunks.append(coefs)
+                C.memmove(d.qt[c], info.qt[c], 128)
             max_blocks = max(max_blocks, nblocks)
             max_pixels = max(max_pixels, info.width * info.height)
-        coef_dev = torch.from_numpy(np.concatenate(chunks)).to(device, non_blocking=True)
+        coef_dev = staging[:coef_pos].to(device, non_blocking=True)
+        if device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+            ring["events"][turn] = ev
         desc_dev = torch.from_numpy(np.frombuffer(descs, dtype=np.uint8).copy()).to(device, non_blocking=True)
         planes = torch.empty(plane_pos, dtype=torch.uint8, device=device)
         L = hipk.lib()
