@@ -78,7 +78,7 @@ __device__ __forceinline__ int swz_of_row(int row) {
 #endif
 
 template <int BM, int BN, int BK, int EPI, int NST>
-__global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 2 : 3)) void conv_igemm_kernel(ConvArgs p) {
   constexpr int S = BK / 8;            // 16-byte slots per LDS row
   constexpr int ROWB = BK * 2;         // bytes per LDS row
   constexpr int RPI = 1024 / ROWB;     // rows covered by one wave-instruction
@@ -279,13 +279,17 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs p) {
   // ---- epilogue: bias / relu / bn partial statistics / bf16 rows via LDS ----
   // Row readback geometry: a wave-instruction covers RPP rows x CPR 16-byte chunks; lane -> (row, chunk)
   // is the same in every pass, so a lane keeps one chunk column (8 channels).
-  constexpr int CPR = WN / 8;         // 16-byte chunks per row
+  // CPR (chunk slots per row) is the row's chunk count rounded up to a power of two, so that lane -> (row,
+  // chunk) is a shift / mask; for WN = 96 four of the 16 slots are idle.
+  constexpr int CHUNKS = WN / 8;      // 16-byte chunks per row
+  constexpr int CPR = CHUNKS <= 4 ? 4 : (CHUNKS <= 8 ? 8 : 16);
   constexpr int RPP = 64 / CPR;       // rows per pass
   constexpr int NP = WM / RPP;        // passes
+  const bool chunk_live = (lane % CPR) < CHUNKS;
   const int chunk_co = n0 + wc * WN + (lane % CPR) * 8;
   auto out_offset = [&](int pass, bool& ok) -> size_t {
     const int m = m0 + wr * WM + pass * RPP + lane / CPR;
-    ok = m < p.M && chunk_co < p.Cout;
+    ok = m < p.M && chunk_co < p.Cout && chunk_live;
     size_t opixel = 0;
     if (ok) {
       if (p.dense_out) {
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs p) {
   if (EPI == 3) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const bool ok = chunk_co + j < p.Cout;
+      const bool ok = chunk_co + j < p.Cout && chunk_live;
       bs1[j] = bs2[j] = 0.f;
       bmu[j] = ok ? p.bn_mean[chunk_co + j] : 0.f;
       bis[j] = ok ? p.bn_invstd[chunk_co + j] : 0.f;
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs p) {
     }
     const int co = chunk_co;
     float* mine = xch + (wc * WN + (lane % CPR) * 8) * 2;
-    if (wr == 1 && lane < CPR) {
+    if (wr == 1 && lane < CHUNKS) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         mine[j * 2] = bs1[j];
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs p) {
       }
     }
     __syncthreads();
-    if (wr == 0 && lane < CPR && co < p.Cout) {
+    if (wr == 0 && lane < CHUNKS && co < p.Cout) {
       const size_t prow = (size_t)tile_m * 2;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -502,6 +506,8 @@ extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int ns
     if (nst == 2) return launch_conv_epi<BM_, BN_, BK_, 2>(*a, stream);                       \
     if (nst == 3) return launch_conv_epi<BM_, BN_, BK_, 3>(*a, stream);                       \
   }
+  CASE(128, 192, 32)
+  CASE(128, 192, 64)
   CASE(128, 128, 32)
   CASE(128, 64, 32)
   CASE(64, 64, 32)

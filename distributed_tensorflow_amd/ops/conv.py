@@ -151,7 +151,7 @@ def get_plan(ih, iw, cin, cout, kh, kw, sy, sx, pads, device) -> ConvPlan:
 # --------------------------------------------------------------------------
 # tile selection
 # --------------------------------------------------------------------------
-_FWD_TILES = {(128, 128), (128, 64), (64, 64)}
+_FWD_TILES = {(128, 192), (128, 128), (128, 64), (64, 64)}
 
 
 def _env_tile(name: str):
@@ -163,20 +163,21 @@ def _env_tile(name: str):
 
 def pick_fwd_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
     """(BM, BN, BK, LDS stages) of the implicit-GEMM kernel.  Chosen from a sweep over the ResNet-50 layer shapes
-    at batch 256 on MI355X (tools/sweep_conv.py): deep reductions (3x3 convs, K >= 576) want BK = 64;
-    short ones (1x1 convs, memory-bound) want BK = 32 and the higher occupancy it allows; the 256-row
+    and Inception-v3 layer shapes on MI355X (tools/sweep_conv.py, profiles/tile_sweep_b256.md); a 256-row
     tile never won."""
     forced = _env_tile("DTFA_CONV_TILE")
     if forced:
         return tuple(forced) if len(forced) == 4 else tuple(forced) + (2,)  # type: ignore[return-value]
-    bk = 64 if K >= 576 else 32
-    bn = 128 if cout > 64 else 64
+    # k-depth: deep reductions amortise the per-tile barrier with BK = 64 (two 32 KB stages, two workgroups per
+    # CU); below K = 1024 three 16 KB stages (two k-tiles of loads in flight, three workgroups per CU) win.
+    bk = 64 if K >= 1024 else 32
+    # width: channel counts that are multiples of 192 (Inception: 192, 384) get the 192-wide tile, which
+    # wastes no columns; otherwise 128, or 64 for narrow outputs
+    bn = 192 if cout % 192 == 0 else (128 if cout > 64 else 64)
     bm = 128
     tiles = -(-M // bm) * -(-cout // bn)
     if bn == 64 and tiles < 512:
         bm = 64
-    # deep tiles: two 32 KB stages (two workgroups per CU); shallow ones: three 16 KB stages, which keeps
-    # two k-tiles of loads in flight at three workgroups per CU
     return bm, bn, bk, (2 if bk == 64 else 3)
 
 

@@ -38,6 +38,44 @@ RESNET = [
 ]
 
 
+# Inception-v3 at 299x299: (H, W, Cin, Cout, (kh, kw), stride, (top, bottom, left, right)); each shape's weight in
+# the trunk (how many layers have it) is the last entry.
+INCEPTION = [
+    (149, 149, 32, 32, (3, 3), 1, (0, 0, 0, 0), 1),
+    (147, 147, 32, 64, (3, 3), 1, (1, 1, 1, 1), 1),
+    (73, 73, 64, 80, (1, 1), 1, (0, 0, 0, 0), 1),
+    (73, 73, 80, 192, (3, 3), 1, (0, 0, 0, 0), 1),
+    (35, 35, 288, 64, (1, 1), 1, (0, 0, 0, 0), 7),
+    (35, 35, 288, 48, (1, 1), 1, (0, 0, 0, 0), 3),
+    (35, 35, 48, 64, (5, 5), 1, (2, 2, 2, 2), 3),
+    (35, 35, 64, 96, (3, 3), 1, (1, 1, 1, 1), 4),
+    (35, 35, 96, 96, (3, 3), 1, (1, 1, 1, 1), 3),
+    (35, 35, 288, 384, (3, 3), 2, (0, 0, 0, 0), 1),
+    (17, 17, 768, 192, (1, 1), 1, (0, 0, 0, 0), 12),
+    (17, 17, 768, 160, (1, 1), 1, (0, 0, 0, 0), 4),
+    (17, 17, 768, 128, (1, 1), 1, (0, 0, 0, 0), 2),
+    (17, 17, 160, 160, (1, 7), 1, (0, 0, 3, 3), 6),
+    (17, 17, 160, 192, (7, 1), 1, (3, 3, 0, 0), 4),
+    (17, 17, 192, 192, (1, 7), 1, (0, 0, 3, 3), 8),
+    (17, 17, 128, 128, (7, 1), 1, (3, 3, 0, 0), 3),
+    (17, 17, 192, 320, (3, 3), 2, (0, 0, 0, 0), 1),
+    (8, 8, 1280, 320, (1, 1), 1, (0, 0, 0, 0), 1),
+    (8, 8, 2048, 384, (1, 1), 1, (0, 0, 0, 0), 2),
+    (8, 8, 2048, 448, (1, 1), 1, (0, 0, 0, 0), 1),
+    (8, 8, 448, 384, (3, 3), 1, (1, 1, 1, 1), 2),
+    (8, 8, 384, 384, (1, 3), 1, (0, 0, 1, 1), 8),
+    (8, 8, 2048, 192, (1, 1), 1, (0, 0, 0, 0), 1),
+]
+
+
+def normalise(shape):
+    """(H, W, Cin, Cout, (kh, kw), stride, pads4, weight) from either table's row format."""
+    H, W, Cin, Cout, k, s, pad = shape[:7]
+    k = (k, k) if isinstance(k, int) else tuple(k)
+    pad = (pad,) * 4 if isinstance(pad, int) else tuple(pad)
+    return H, W, Cin, Cout, k, s, pad, (shape[7] if len(shape) > 7 else 1)
+
+
 def timeit(fn, iters):
     fn()
     torch.cuda.synchronize()
@@ -54,27 +92,32 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--reference", action="store_true")
     ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--shapes", default="resnet", choices=["resnet", "inception"])
+    ap.add_argument("--fwd_only", action="store_true")
     args = ap.parse_args()
     B = args.batch
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0, "ref_fwd": 0.0, "ref_bwd": 0.0}
     print("%-28s %8s | %8s %7s | %8s %7s | %8s %7s" % ("shape", "GFLOP", "fwd us", "TF/s", "dgrad us", "TF/s", "wgrad us", "TF/s"))
-    for i, (H, W, Cin, Cout, k, s, pad) in enumerate(RESNET):
+    table = RESNET if args.shapes == "resnet" else INCEPTION
+    for i, shape in enumerate(table):
         if args.only >= 0 and i != args.only:
             continue
-        pads = (pad, pad, pad, pad)
-        plan = cv.get_plan(H, W, Cin, Cout, k, k, s, s, pads, "cuda")
+        H, W, Cin, Cout, (kh, kw), s, pads, weight = normalise(shape)
+        pad = pads[0]
+        plan = cv.get_plan(H, W, Cin, Cout, kh, kw, s, s, pads, "cuda")
         x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
-        w = (torch.randn(Cout, k, k, Cin, device="cuda") * 0.05).bfloat16()
+        w = (torch.randn(Cout, kh, kw, Cin, device="cuda") * 0.05).bfloat16()
         dy = torch.randn(B, plan.oh, plan.ow, Cout, device="cuda").bfloat16()
-        flop = 2.0 * B * plan.oh * plan.ow * Cout * k * k * Cin
+        flop = 2.0 * B * plan.oh * plan.ow * Cout * kh * kw * Cin
         tf = timeit(lambda: cv.conv_fwd(x, w, plan, want_stats=True), args.iters)
-        td = timeit(lambda: cv.conv_dgrad(dy, w, plan), args.iters) if i > 0 else 0.0
-        tw = timeit(lambda: cv.conv_wgrad(x, dy, plan), args.iters)
-        tot["fwd"] += tf; tot["dgrad"] += td; tot["wgrad"] += tw
+        td = timeit(lambda: cv.conv_dgrad(dy, w, plan), args.iters) if (Cin > 8 and not args.fwd_only) else 0.0
+        tw = timeit(lambda: cv.conv_wgrad(x, dy, plan), args.iters) if not args.fwd_only else 0.0
+        tot["fwd"] += tf * weight; tot["dgrad"] += td * weight; tot["wgrad"] += tw * weight
+        k = kh
         line = "%-28s %8.2f | %8.1f %7.1f | %8.1f %7.1f | %8.1f %7.1f" % (
-            "%dx%d %d->%d k%d s%d" % (H, W, Cin, Cout, k, s), flop / 1e9,
-            tf * 1e6, flop / tf / 1e12, td * 1e6, (flop / td / 1e12) if td else 0.0, tw * 1e6, flop / tw / 1e12)
-        if args.reference:
+            "%dx%d %d->%d k%dx%d s%d" % (H, W, Cin, Cout, kh, kw, s), flop / 1e9,
+            tf * 1e6, flop / tf / 1e12, td * 1e6, (flop / td / 1e12) if td else 0.0, tw * 1e6, (flop / tw / 1e12) if tw else 0.0)
+        if args.reference and kh == kw:
             xn = x.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last).requires_grad_(i > 0)
             wn = w.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last).requires_grad_(True)
             conv = lambda: torch.nn.functional.conv2d(xn, wn, stride=s, padding=pad)
