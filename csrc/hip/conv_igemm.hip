@@ -238,11 +238,13 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 2 : 3)) void conv_igemm
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt][0] += (float)af[src][mt][0] * (float)bfr[src][nt][0];
 #else
+    __builtin_amdgcn_s_setprio(1);  // a wave that has its operands keeps the MFMA pipe ahead of waves issuing loads
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[src][mt], bfr[src][nt], acc[mt][nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
 #endif
   };
 

@@ -166,7 +166,7 @@ class Saver:
 
     # ------------------------------------------------------------------ save
     def save(self, checkpoint_dir: str, global_step: int, write_state: bool = True,
-             extra: Optional[Dict[str, np.ndarray]] = None) -> str:
+             extra: Optional[Dict[str, np.ndarray]] = None, write_meta: bool = True) -> str:
         os.makedirs(checkpoint_dir, exist_ok=True)
         tensors = self.variables()
         tensors["global_step"] = np.array(int(global_step), dtype=np.int64)
@@ -179,6 +179,15 @@ class Saver:
         base = "%s-%d" % (self.basename, int(global_step))
         prefix = os.path.join(checkpoint_dir, base)
         bundle.write_bundle(prefix, tensors)
+        if write_meta:
+            from .metagraph import encode_meta_graph
+
+            trainable = {v.name: v.trainable for v in self.specs}
+            names = [(n, trainable.get(n, False)) for n in sorted(tensors, key=lambda k: k.encode())]
+            tmp = prefix + ".meta.tmp%d" % os.getpid()
+            with open(tmp, "wb") as f:
+                f.write(encode_meta_graph(names, self.max_to_keep))
+            os.replace(tmp, prefix + ".meta")
         if write_state:
             bundle.update_checkpoint_state(checkpoint_dir, base, self.max_to_keep)
         return prefix

@@ -132,3 +132,27 @@ def test_model_only_checkpoint_is_subset_restore(tmp_path):
     model.eval(); fresh.eval()
     with torch.no_grad():
         torch.testing.assert_close(model(x)[0], fresh(x)[0])
+
+
+def test_meta_file_lists_the_saved_variables(tmp_path):
+    """Every checkpoint comes with a ``.meta`` (MetaGraphDef wire format): SaverDef V2 and the variable
+    collections, so the file set is the one ``tf.train.Saver`` leaves behind."""
+    from distributed_tensorflow_amd.io.metagraph import decode_meta_graph
+
+    torch.manual_seed(0)
+    model = build_model("flower_cnn", widths=(8, 8, 16, 16, 32))
+    eng = DataParallelEngine(model, mode="sync_dp", optimizer="adam", lr=1e-3)
+    saver = Saver(model, eng)
+    prefix = saver.save(str(tmp_path), 7)
+    files = sorted(os.listdir(tmp_path))
+    assert files == ["checkpoint", "model.ckpt-7.data-00000-of-00001", "model.ckpt-7.index", "model.ckpt-7.meta"]
+    meta = decode_meta_graph(open(prefix + ".meta", "rb").read())
+    assert meta["tags"] == ["train"] and meta["saver"]["version"] == 2 and meta["saver"]["max_to_keep"] == 5
+    assert meta["saver"]["restore_op_name"] == "save/restore_all"
+    names = {n for n, _ in meta["collections"]["variables"]}
+    keys = {k + ":0" for k in bundle.read_bundle(prefix)}
+    assert names == keys
+    trainable = {n for n, _ in meta["collections"]["trainable_variables"]}
+    assert "fc_trainable/flower_logits/kernel:0" in trainable and "FlowerCNN/conv1/BatchNorm/moving_mean:0" not in trainable
+    assert "fc_trainable/flower_logits/kernel/Adam:0" in names and "fc_trainable/flower_logits/kernel/Adam:0" not in trainable
+    assert meta["collections"]["global_step"] == [("global_step:0", False)]
