@@ -71,213 +71,21 @@ __device__ __forceinline__ int swz_of_row(int row) {
 // EPI selects the epilogue at compile time: 0 = plain store (data-gradient, no statistics),
 // 1 = batch-norm partial statistics, 2 = bias (+ optional ReLU), 3 = data-gradient that also emits the
 // batch-norm backward partial sums of the layer its output flows into.
-// Timing-only builds for attributing main-loop time (results are wrong): -DDTFA_DBG=1 drops the global
-// loads of the main loop, =2 replaces the MFMAs by one scalar FMA per fragment pair, =3 both.
-#ifndef DTFA_DBG
-#define DTFA_DBG 0
-#endif
-
-template <int BM, int BN, int BK, int EPI, int NST>
-__global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 2 : 3)) void conv_igemm_kernel(ConvArgs p) {
-  constexpr int S = BK / 8;            // 16-byte slots per LDS row
-  constexpr int ROWB = BK * 2;         // bytes per LDS row
-  constexpr int RPI = 1024 / ROWB;     // rows covered by one wave-instruction
-  constexpr int NA = BM * ROWB / 4096; // LDS-DMA instructions per thread (A)
-  constexpr int NB = BN * ROWB / 4096;
+// Epilogue shared by the kernels below.  ``acc`` is the wave's MT x NT grid of 32x32 accumulators for the
+// tile at (m0, n0); ``w4`` is the wave's index inside its 2x2 group and ``lds_tiles`` that group's LDS
+// region (at least 4 * (BM/2) * EP_PITCH + BN*8 bytes), free for reuse.  ``valid`` is false for a group
+// that has no tile (it still takes part in the barriers).  Bias / ReLU / batch-norm statistics / bf16 rows
+// staged through LDS so that global stores are 16 B per lane.
+template <int BM, int BN, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[BM / 64][BN / 64], char* lds_tiles,
+                                              int w4, int lane, int m0, int n0, unsigned tile_m, bool valid) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 32, NT = WN / 32;
-  constexpr int KS = BK / 16;
-  constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int EP_PITCH = WN * 2 + 16;
-  static_assert(NA >= 1 && NB >= 1, "tile too small for 256-thread staging");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* lds_taps = (int*)smem;
-  char* lds_tiles = smem + MAX_TAPS * 4;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 1, wc = wid & 1;
-
-  const unsigned mtiles = (p.M + BM - 1) / BM;
-  const unsigned ntiles = (p.Cout + BN - 1) / BN;
-  const unsigned bid = xcd_remap(blockIdx.x, mtiles * ntiles);
-  const unsigned tile_m = bid / ntiles, tile_n = bid % ntiles;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  if (tid < p.T) lds_taps[tid] = p.taps[tid];
-
-  // ---- per-thread staging rows (fixed across the K loop) ----
-  const int slot = lane % S;
-  const int row_in_inst = lane / S;
-  const int cslot = slot ^ swz_of_row<BK>(wid * RPI + row_in_inst);  // same for every i
-
-  const bf16* abase[NA];
-  int aiy[NA], aix[NA];
-  const int opix = p.OYn * p.OXn;
-  // 1x1 / stride-1 / unpadded: input pixel == output pixel == m, no decode and no bounds checks
-  const bool pointwise = p.pointwise != 0;
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    int m = m0 + (i * 4 + wid) * RPI + row_in_inst;
-    if (pointwise) {
-      aiy[i] = m < p.M ? 0 : -(1 << 24);
-      aix[i] = 0;
-      abase[i] = p.x + (size_t)(m < p.M ? m : 0) * p.Cin;
-    } else if (m < p.M) {
-      int b = m / opix;
-      int rem = m - b * opix;
-      int oy = rem / p.OXn;
-      int ox = rem - oy * p.OXn;
-      aiy[i] = oy * p.isy;
-      aix[i] = ox * p.isx;
-      abase[i] = p.x + (size_t)b * p.IH * p.IW * p.Cin;
-    } else {
-      aiy[i] = -(1 << 24);
-      aix[i] = 0;
-      abase[i] = p.x;
-    }
-  }
-  const bf16* bbase[NB];
-  bool bok[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    int n = n0 + (i * 4 + wid) * RPI + row_in_inst;
-    bok[i] = n < p.Cout;
-    bbase[i] = p.w + (size_t)(bok[i] ? n : 0) * p.K;
-  }
-
-  __syncthreads();  // tap table visible
-
-  auto stage = [&](int kt, int buf) {
-    char* sa = lds_tiles + buf * STAGE;
-    char* sb = sa + BM * ROWB;
-    const int kc8 = kt * BK + cslot * 8;
-    const bool kvalid = kc8 < p.K;
-    if (pointwise) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const bf16* src = (kvalid && aiy[i] == 0) ? abase[i] + kc8 : p.zero;
-        glds16(src, sa + (i * 4 + wid) * 1024);
-      }
-    } else {
-      const int tap = (int)__umulhi((unsigned)kc8, p.cin_magic);
-      const int ci = kc8 - tap * p.Cin;
-      const int tp = kvalid ? lds_taps[tap] : 0;
-      const int dy = tp >> 16;
-      const int dx = (int)(short)(tp & 0xffff);
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        int iy = aiy[i] + dy, ix = aix[i] + dx;
-        bool ok = kvalid && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-        const bf16* src = ok ? abase[i] + ((size_t)(iy * p.IW + ix) * p.Cin + ci) : p.zero;
-        glds16(src, sa + (i * 4 + wid) * 1024);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const bf16* src = (kvalid && bok[i]) ? bbase[i] + kc8 : p.zero;
-      glds16(src, sb + (i * 4 + wid) * 1024);
-    }
-  };
-
-  // ---- fragment read offsets ----
-  int aoff[MT], aswz[MT], boff[NT], bswz[NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    int row = wr * WM + mt * 32 + (lane & 31);
-    aoff[mt] = row * ROWB;
-    aswz[mt] = swz_of_row<BK>(row);
-  }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    int row = wc * WN + nt * 32 + (lane & 31);
-    boff[nt] = BM * ROWB + row * ROWB;
-    bswz[nt] = swz_of_row<BK>(row);
-  }
+  const int wr = w4 >> 1, wc = w4 & 1;
+  const int wid = w4;
   const int khalf = lane >> 5;
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
-
-  const int KT = (p.K + BK - 1) / BK;
-  constexpr int LPS = NA + NB;  // LDS-DMA loads per thread and stage
-  static_assert(KS % 2 == 0, "fragment double-buffering assumes an even number of k-steps per tile");
-  // NST LDS stages (2 or 3): while k-tile kt is multiplied, the tiles up to kt+NST-1 are in flight.
-  // Within a tile the fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks run, and
-  // the first fragments of tile kt+1 are read behind the barrier, ahead of the last MFMAs of tile kt.
-  static_assert(NST == 2 || NST == 3, "two or three LDS stages");
-  stage(0, 0);
-  if (NST == 3 && KT > 1) {
-    stage(1, 1);
-    wait_vmcnt<LPS>();
-  } else {
-    wait_vmcnt<0>();
-  }
-  __syncthreads();
-
-  bf16x8 af[2][MT], bfr[2][NT];
-  auto read_frags = [&](int buf, int ks, int dst) {
-    const char* base = lds_tiles + buf * STAGE;
-    const int sl = ks * 2 + khalf;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) af[dst][mt] = *(const bf16x8*)(base + aoff[mt] + ((sl ^ aswz[mt]) << 4));
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bfr[dst][nt] = *(const bf16x8*)(base + boff[nt] + ((sl ^ bswz[nt]) << 4));
-  };
-  auto mfma_step = [&](int src) {
-#if (DTFA_DBG & 2)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt][0] += (float)af[src][mt][0] * (float)bfr[src][nt][0];
-#else
-    __builtin_amdgcn_s_setprio(1);  // a wave that has its operands keeps the MFMA pipe ahead of waves issuing loads
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[src][mt], bfr[src][nt], acc[mt][nt], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-#endif
-  };
-
-  read_frags(0, 0, 0);
-  int cur = 0;  // kt % NST
-  for (int kt = 0; kt < KT; ++kt) {
-    const int nxt = cur == NST - 1 ? 0 : cur + 1;
-    // the slot requested here held tile kt-1, which every wave finished reading before the last barrier
-    if (kt + NST - 1 < KT && !(DTFA_DBG & 1)) stage(kt + NST - 1, NST == 2 ? nxt : (nxt == 2 ? 0 : nxt + 1));
-#pragma unroll
-    for (int ks = 0; ks + 1 < KS; ++ks) {
-      read_frags(cur, ks + 1, (ks + 1) & 1);
-      // keep the reads ahead of the MFMAs: left alone the scheduler sinks them and reuses one register set
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_step(ks & 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (kt + 1 < KT) {
-      // this wave's reads of tile kt are complete and everything but the stage just requested has landed;
-      // after the barrier tile kt+1 is visible to all waves and tile kt's slot may be overwritten
-      // (a raw barrier: __syncthreads() would add a fence that drains every outstanding LDS-DMA load)
-      if (NST == 3 && kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      read_frags(nxt, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    mfma_step((KS - 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    cur = nxt;
-  }
-  __syncthreads();  // all fragment reads done before the tiles are reused by the epilogue
-
+  const int opix = p.OYn * p.OXn;
   // ---- epilogue: bias / relu / bn partial statistics / bf16 rows via LDS ----
   // Row readback geometry: a wave-instruction covers RPP rows x CPR 16-byte chunks; lane -> (row, chunk)
   // is the same in every pass, so a lane keeps one chunk column (8 channels).
@@ -347,7 +155,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 2 : 3)) void conv_igemm
     }
   }
   __syncthreads();
-  if (EPI == 1 && wr == 0 && khalf == 0) {
+  if (EPI == 1 && wr == 0 && khalf == 0 && valid) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int co = n0 + wc * WN + nt * 32 + colq;
@@ -452,7 +260,7 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 2 : 3)) void conv_igemm
       }
     }
     __syncthreads();
-    if (wr == 0 && lane < CHUNKS && co < p.Cout) {
+    if (wr == 0 && lane < CHUNKS && co < p.Cout && valid) {
       const size_t prow = (size_t)tile_m * 2;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -463,33 +271,262 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 2 : 3)) void conv_igemm
   }
 }
 
-template <int BM, int BN, int BK, int EPI, int NST>
+// Timing-only builds for attributing main-loop time (results are wrong): -DDTFA_DBG=1 drops the global
+// loads of the main loop, =2 replaces the MFMAs by one scalar FMA per fragment pair, =3 both.
+#ifndef DTFA_DBG
+#define DTFA_DBG 0
+#endif
+
+// WG = 2 doubles the workgroup: 512 threads as two groups of 2 x 2 waves, each group computing its own
+// BM-row tile of a (2 * BM) x BN macro tile against ONE shared BN-column weight tile.  The kernel moves
+// (WG * BM + BN) * BK operand bytes from L2 into LDS per WG * BM * BN * BK multiply-adds; that path (measured
+// ~12 TB/s chip-wide with ~90 % L2 hits) is what bounds the compute-heavy layers, and sharing the weight tile
+// takes a quarter of the bytes per FLOP away at 128 x 128.
+template <int BM, int BN, int BK, int EPI, int NST, int WG>
+__global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 : 3))) void conv_igemm_kernel(ConvArgs p) {
+  constexpr int S = BK / 8;            // 16-byte slots per LDS row
+  constexpr int ROWB = BK * 2;         // bytes per LDS row
+  constexpr int RPI = 1024 / ROWB;     // rows covered by one wave-instruction
+  constexpr int NA = BM * ROWB / 4096; // LDS-DMA instructions per thread (A)
+  constexpr int NB = BN * ROWB / 4096;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int MT = WM / 32, NT = WN / 32;
+  constexpr int KS = BK / 16;
+  constexpr int STAGE = (WG * BM + BN) * ROWB;   // [A of group 0][A of group 1][B]
+  constexpr int NBW = NB / WG;                   // weight-tile loads per wave
+  constexpr int EP = 4 * (BM / 2) * ((BN / 2) * 2 + 16) + 2 * (BN / 2) * 2 * 4;  // epilogue bytes per group
+  static_assert(NA >= 1 && NBW >= 1 && NB % WG == 0, "tile too small for this staging");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* lds_taps = (int*)smem;
+  char* lds_tiles = smem + MAX_TAPS * 4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = WG == 1 ? 0 : wid_all >> 2;   // wave group
+  const int wid = wid_all & 3;    // wave inside its 2 x 2 group
+  const int wr = wid >> 1, wc = wid & 1;
+
+  const unsigned mtiles = (p.M + BM - 1) / BM;
+  const unsigned mgroups = (mtiles + WG - 1) / WG;
+  const unsigned ntiles = (p.Cout + BN - 1) / BN;
+  const unsigned bid = xcd_remap(blockIdx.x, mgroups * ntiles);
+  const unsigned tile_m = (bid / ntiles) * WG + grp, tile_n = bid % ntiles;
+  const bool valid = tile_m < mtiles;   // the last macro tile may have a group without rows
+  const int m0 = valid ? (int)(tile_m * BM) : p.M, n0 = tile_n * BN;
+
+  if (tid < p.T) lds_taps[tid] = p.taps[tid];
+
+  // ---- per-thread staging rows (fixed across the K loop) ----
+  const int slot = lane % S;
+  const int row_in_inst = lane / S;
+  const int cslot = slot ^ swz_of_row<BK>(wid * RPI + row_in_inst);  // same for every i
+
+  const bf16* abase[NA];
+  int aiy[NA], aix[NA];
+  const int opix = p.OYn * p.OXn;
+  // 1x1 / stride-1 / unpadded: input pixel == output pixel == m, no decode and no bounds checks
+  const bool pointwise = p.pointwise != 0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    int m = m0 + (i * 4 + wid) * RPI + row_in_inst;
+    if (pointwise) {
+      aiy[i] = m < p.M ? 0 : -(1 << 24);
+      aix[i] = 0;
+      abase[i] = p.x + (size_t)(m < p.M ? m : 0) * p.Cin;
+    } else if (m < p.M) {
+      int b = m / opix;
+      int rem = m - b * opix;
+      int oy = rem / p.OXn;
+      int ox = rem - oy * p.OXn;
+      aiy[i] = oy * p.isy;
+      aix[i] = ox * p.isx;
+      abase[i] = p.x + (size_t)b * p.IH * p.IW * p.Cin;
+    } else {
+      aiy[i] = -(1 << 24);
+      aix[i] = 0;
+      abase[i] = p.x;
+    }
+  }
+  // the weight tile's loads are dealt over all waves of the workgroup (the swizzle of a row repeats every
+  // 16 rows, so wave wid_all stages with the same column slot as wave wid)
+  const bf16* bbase[NBW];
+  bool bok[NBW];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    int n = n0 + (i * 4 * WG + wid_all) * RPI + row_in_inst;
+    bok[i] = n < p.Cout;
+    bbase[i] = p.w + (size_t)(bok[i] ? n : 0) * p.K;
+  }
+
+  __syncthreads();  // tap table visible
+
+  auto stage = [&](int kt, int buf) {
+    char* sa = lds_tiles + buf * STAGE + grp * (BM * ROWB);
+    char* sb = lds_tiles + buf * STAGE + WG * BM * ROWB;
+    const int kc8 = kt * BK + cslot * 8;
+    const bool kvalid = kc8 < p.K;
+    if (pointwise) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const bf16* src = (kvalid && aiy[i] == 0) ? abase[i] + kc8 : p.zero;
+        glds16(src, sa + (i * 4 + wid) * 1024);
+      }
+    } else {
+      const int tap = (int)__umulhi((unsigned)kc8, p.cin_magic);
+      const int ci = kc8 - tap * p.Cin;
+      const int tp = kvalid ? lds_taps[tap] : 0;
+      const int dy = tp >> 16;
+      const int dx = (int)(short)(tp & 0xffff);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        int iy = aiy[i] + dy, ix = aix[i] + dx;
+        bool ok = kvalid && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const bf16* src = ok ? abase[i] + ((size_t)(iy * p.IW + ix) * p.Cin + ci) : p.zero;
+        glds16(src, sa + (i * 4 + wid) * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+      const bf16* src = (kvalid && bok[i]) ? bbase[i] + kc8 : p.zero;
+      glds16(src, sb + (i * 4 * WG + wid_all) * 1024);
+    }
+  };
+
+  // ---- fragment read offsets ----
+  int aoff[MT], aswz[MT], boff[NT], bswz[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int row = wr * WM + mt * 32 + (lane & 31);
+    aoff[mt] = grp * (BM * ROWB) + row * ROWB;
+    aswz[mt] = swz_of_row<BK>(row);
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int row = wc * WN + nt * 32 + (lane & 31);
+    boff[nt] = WG * BM * ROWB + row * ROWB;
+    bswz[nt] = swz_of_row<BK>(row);
+  }
+  const int khalf = lane >> 5;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+
+  const int KT = (p.K + BK - 1) / BK;
+  constexpr int LPS = NA + NBW;  // LDS-DMA loads per thread and stage
+  static_assert(KS % 2 == 0, "fragment double-buffering assumes an even number of k-steps per tile");
+  // NST LDS stages (2 or 3): while k-tile kt is multiplied, the tiles up to kt+NST-1 are in flight.
+  // Within a tile the fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks run, and
+  // the first fragments of tile kt+1 are read behind the barrier, ahead of the last MFMAs of tile kt.
+  static_assert(NST == 2 || NST == 3, "two or three LDS stages");
+  stage(0, 0);
+  if (NST == 3 && KT > 1) {
+    stage(1, 1);
+    wait_vmcnt<LPS>();
+  } else {
+    wait_vmcnt<0>();
+  }
+  __syncthreads();
+
+  bf16x8 af[2][MT], bfr[2][NT];
+  auto read_frags = [&](int buf, int ks, int dst) {
+    const char* base = lds_tiles + buf * STAGE;
+    const int sl = ks * 2 + khalf;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[dst][mt] = *(const bf16x8*)(base + aoff[mt] + ((sl ^ aswz[mt]) << 4));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bfr[dst][nt] = *(const bf16x8*)(base + boff[nt] + ((sl ^ bswz[nt]) << 4));
+  };
+  auto mfma_step = [&](int src) {
+#if (DTFA_DBG & 2)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt][0] += (float)af[src][mt][0] * (float)bfr[src][nt][0];
+#else
+    __builtin_amdgcn_s_setprio(1);  // a wave that has its operands keeps the MFMA pipe ahead of waves issuing loads
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[src][mt], bfr[src][nt], acc[mt][nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+
+  read_frags(0, 0, 0);
+  int cur = 0;  // kt % NST
+  for (int kt = 0; kt < KT; ++kt) {
+    const int nxt = cur == NST - 1 ? 0 : cur + 1;
+    // the slot requested here held tile kt-1, which every wave finished reading before the last barrier
+    if (kt + NST - 1 < KT && !(DTFA_DBG & 1)) stage(kt + NST - 1, NST == 2 ? nxt : (nxt == 2 ? 0 : nxt + 1));
+#pragma unroll
+    for (int ks = 0; ks + 1 < KS; ++ks) {
+      read_frags(cur, ks + 1, (ks + 1) & 1);
+      // keep the reads ahead of the MFMAs: left alone the scheduler sinks them and reuses one register set
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kt + 1 < KT) {
+      // this wave's reads of tile kt are complete and everything but the stage just requested has landed;
+      // after the barrier tile kt+1 is visible to all waves and tile kt's slot may be overwritten
+      // (a raw barrier: __syncthreads() would add a fence that drains every outstanding LDS-DMA load)
+      if (NST == 3 && kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      read_frags(nxt, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_step((KS - 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+  }
+  __syncthreads();  // all fragment reads done before the tiles are reused by the epilogue
+
+  // each group stages its output through its own part of the (now idle) tile area
+  conv_epilogue<BM, BN, EPI>(p, acc, lds_tiles + grp * EP, wid, lane, m0, n0, tile_m, valid);
+}
+
+template <int BM, int BN, int BK, int EPI, int NST, int WG>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   constexpr int ROWB = BK * 2;
-  constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int EP = 4 * (BM / 2) * ((BN / 2) * 2 + 16) + 2 * (BN / 2) * 2 * 4;  // row tiles + statistics exchange
+  constexpr int STAGE = (WG * BM + BN) * ROWB;
+  constexpr int EP = WG * (4 * (BM / 2) * ((BN / 2) * 2 + 16) + 2 * (BN / 2) * 2 * 4);  // row tiles + statistics exchange
   size_t lds = MAX_TAPS * 4 + (size_t)((NST * STAGE > EP) ? NST * STAGE : EP);
   unsigned mtiles = (a.M + BM - 1) / BM, ntiles = (a.Cout + BN - 1) / BN;
+  unsigned mgroups = (mtiles + WG - 1) / WG;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, EPI, NST>,
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, EPI, NST, WG>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, EPI, NST>), dim3(mtiles * ntiles), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, EPI, NST, WG>), dim3(mgroups * ntiles), dim3(256 * WG), lds,
+                     stream, a);
   return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int BK, int NST>
+template <int BM, int BN, int BK, int NST, int WG = 1>
 static int launch_conv_epi(const ConvArgs& a, hipStream_t stream) {
-  if (a.bn_y != nullptr) return launch_conv<BM, BN, BK, 3, NST>(a, stream);
-  if (a.stats != nullptr) return launch_conv<BM, BN, BK, 1, NST>(a, stream);
-  if (a.bias != nullptr || a.relu) return launch_conv<BM, BN, BK, 2, NST>(a, stream);
-  return launch_conv<BM, BN, BK, 0, NST>(a, stream);
+  if (a.bn_y != nullptr) return launch_conv<BM, BN, BK, 3, NST, WG>(a, stream);
+  if (a.stats != nullptr) return launch_conv<BM, BN, BK, 1, NST, WG>(a, stream);
+  if (a.bias != nullptr || a.relu) return launch_conv<BM, BN, BK, 2, NST, WG>(a, stream);
+  return launch_conv<BM, BN, BK, 0, NST, WG>(a, stream);
 }
 
-// Number of partial-statistics rows the kernel writes for a given M and BM (one per row of tiles).
-extern "C" int dtfa_conv_stats_rows(int M, int bm) { return (M + bm - 1) / bm; }
+// Number of partial-statistics rows the kernel writes for a given M and BM (one per row of tiles; a 256-row
+// macro tile is two 128-row tiles).
+extern "C" int dtfa_conv_stats_rows(int M, int bm) {
+  if (bm == 256) bm = 128;
+  return (M + bm - 1) / bm;
+}
 
 extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int nst, hipStream_t stream) {
   if (a->Cin % 8 != 0 || a->Cout % 8 != 0 || a->T > MAX_TAPS || a->T < 1) return -1;
@@ -503,6 +540,10 @@ extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int ns
     if (a->bn_relu != 0 && a->bn_relu != 2 && a->bn_relu != 3) return -5;
   }
   if (a->M <= 0) return 0;
+  // bm == 256: two wave groups of 128 rows sharing one weight tile
+  if (bm == 256 && bn == 128 && bk == 32 && nst == 3) return launch_conv_epi<128, 128, 32, 3, 2>(*a, stream);
+  if (bm == 256 && bn == 128 && bk == 32 && nst == 2) return launch_conv_epi<128, 128, 32, 2, 2>(*a, stream);
+  if (bm == 256 && bn == 128 && bk == 64 && nst == 2) return launch_conv_epi<128, 128, 64, 2, 2>(*a, stream);
 #define CASE(BM_, BN_, BK_)                                                                   \
   if (bm == BM_ && bn == BN_ && bk == BK_) {                                                  \
     if (nst == 2) return launch_conv_epi<BM_, BN_, BK_, 2>(*a, stream);                       \

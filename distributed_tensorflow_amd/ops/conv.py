@@ -154,6 +154,13 @@ def get_plan(ih, iw, cin, cout, kh, kw, sy, sx, pads, device) -> ConvPlan:
 _FWD_TILES = {(128, 192), (128, 128), (128, 64), (64, 64)}
 
 
+# 256 x 128 macro tile (512-thread workgroups) for compute-bound layers.
+_WIDE = os.environ.get("DTFA_CONV_WIDE", "1") == "1"
+_WIDE_MIN_K = int(os.environ.get("DTFA_CONV_WIDE_MIN_K", "256"))
+_WIDE_MIN_TILES = int(os.environ.get("DTFA_CONV_WIDE_MIN_TILES", "1024"))
+_WIDE_BK = int(os.environ.get("DTFA_CONV_WIDE_BK", "32"))
+
+
 def _env_tile(name: str):
     v = os.environ.get(name)
     if not v:
@@ -178,6 +185,9 @@ def pick_fwd_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
     tiles = -(-M // bm) * -(-cout // bn)
     if bn == 64 and tiles < 512:
         bm = 64
+    if _WIDE and bn == 128 and K >= _WIDE_MIN_K and tiles >= _WIDE_MIN_TILES:
+        # 256-row macro tile: two 128-row wave groups share one weight tile (fewer L2 -> LDS bytes per FLOP)
+        return 256, 128, _WIDE_BK, (2 if _WIDE_BK == 64 else 3)
     return bm, bn, bk, (2 if bk == 64 else 3)
 
 
