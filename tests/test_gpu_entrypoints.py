@@ -80,3 +80,51 @@ def test_collective_trainer_checkpoint_resume_export_on_gpu(tmp_path):
     jpegs = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(data, "*", "*.jpg")))[:3]]
     out = s.predict_images(jpegs)
     assert out["classes"].shape == (3, 1) and np.isfinite(out["scores"]).all()
+
+
+@pytest.mark.gpu
+def test_model_server_on_gpu_matches_servable(tmp_path):
+    """REST server over the HIP inference path: batched answers equal the servable called directly."""
+    import base64
+    import io
+    import json
+    import urllib.request
+
+    import numpy as np
+    import torch
+    from PIL import Image
+
+    from distributed_tensorflow_amd.io.export import Servable, export_servable
+    from distributed_tensorflow_amd.models import build_model
+    from distributed_tensorflow_amd.serving import ModelManager, ModelServer
+
+    classes = ["daisy", "dandelion", "roses", "sunflowers", "tulips"]
+    torch.manual_seed(0)
+    model = build_model("flower_cnn", num_classes=5, device=torch.device("cuda"))
+    export_servable(model, classes, str(tmp_path / "m"), 1, model_name="flower_cnn", image_size=64)
+    rng = np.random.default_rng(0)
+    jpegs = []
+    for i in range(10):
+        b = io.BytesIO()
+        Image.fromarray(rng.integers(0, 255, (80 + 8 * i, 96, 3), dtype=np.uint8)).save(b, format="JPEG", quality=90)
+        jpegs.append(b.getvalue())
+    ref = Servable(str(tmp_path / "m" / "1"), device="cuda", hip_graphs=False).predict_images(jpegs)
+    # the graph-replayed forward (bucket 16 for 10 images, then bucket 4 twice) equals the eager one
+    graphed = Servable(str(tmp_path / "m" / "1"), device="cuda", hip_graphs=True)
+    for chunk in (jpegs, jpegs[:3], jpegs[3:6]):
+        a, b = graphed.predict_images(chunk), Servable.predict_images(graphed, chunk)
+        assert a["classes"].tolist() == b["classes"].tolist() and np.array_equal(a["scores"], b["scores"])
+    got = graphed.predict_images(jpegs)
+    assert sorted(graphed._graphs) == [4, 16]
+    assert got["classes"].tolist() == ref["classes"].tolist() and np.allclose(got["scores"], ref["scores"], atol=2e-2)
+    manager = ModelManager(str(tmp_path / "m"), "flowers", device="cuda", poll_seconds=0).start()
+    server = ModelServer(manager, port=0, max_batch=4, batch_timeout_ms=5.0).start()
+    try:
+        body = json.dumps({"instances": [{"b64": base64.b64encode(j).decode()} for j in jpegs]}).encode()
+        with urllib.request.urlopen("http://127.0.0.1:%d/v1/models/flowers:predict" % server.port, body, timeout=120) as r:
+            out = json.loads(r.read())
+        assert [p["classes"] for p in out["predictions"]] == ref["classes"].tolist()
+        assert np.allclose([p["scores"] for p in out["predictions"]], ref["scores"], atol=2e-2)
+        assert server.batcher.stats()["batches"] == 3  # 10 images in chunks of max_batch = 4
+    finally:
+        server.stop()

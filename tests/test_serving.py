@@ -1,0 +1,207 @@
+"""Model server: REST contract of both signatures, dynamic batching, version hot-swap, error paths (CPU)."""
+import base64
+import glob
+import json
+import os
+import threading
+import time
+import urllib.error
+import urllib.request
+
+import numpy as np
+import pytest
+import torch
+
+from distributed_tensorflow_amd.io.export import Servable, example_from_jpeg, export_servable
+from distributed_tensorflow_amd.models import build_model
+from distributed_tensorflow_amd.serving import DynamicBatcher, ModelManager, ModelServer, QueueFull, list_versions
+from test_data import _make_dataset
+
+CLASSES = ["daisy", "roses", "tulips"]
+
+
+def _export(base, version, seed):
+    torch.manual_seed(seed)
+    model = build_model("flower_cnn", num_classes=len(CLASSES), device=torch.device("cpu"))
+    return export_servable(model, CLASSES, str(base), version, model_name="flower_cnn", image_size=32)
+
+
+def _call(port, path, body=None):
+    req = urllib.request.Request("http://127.0.0.1:%d%s" % (port, path),
+                                 data=None if body is None else json.dumps(body).encode())
+    try:
+        with urllib.request.urlopen(req, timeout=60) as r:
+            data = r.read()
+            return r.status, (json.loads(data) if r.headers["Content-Type"].startswith("application/json") else data.decode())
+    except urllib.error.HTTPError as e:
+        return e.code, json.loads(e.read())
+
+
+def _b64(b):
+    return {"b64": base64.b64encode(b).decode()}
+
+
+def _same(a, b):
+    """Predictions agree up to the float rounding that depends on the batch an image rode in."""
+    return ([p["classes"] for p in a] == [p["classes"] for p in b]
+            and np.allclose([p["scores"] for p in a], [p["scores"] for p in b], atol=1e-5))
+
+
+@pytest.fixture()
+def served(tmp_path):
+    data = _make_dataset(str(tmp_path / "flowers"), n_per_class=4)
+    jpegs = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(data, "*", "*.jpg")))[:6]]
+    base = tmp_path / "models"
+    _export(base, 1, seed=1)
+    manager = ModelManager(str(base), "flowers", device="cpu", poll_seconds=0).start()
+    server = ModelServer(manager, port=0, max_batch=8, batch_timeout_ms=20.0).start()
+    yield server, manager, base, jpegs
+    server.stop()
+
+
+def test_batcher_merges_requests_and_splits_results():
+    calls = []
+
+    def fn(items):
+        calls.append(len(items))
+        time.sleep(0.01)
+        return {"y": np.array([[i * 2] for i in items]), "z": np.array([i for i in items])}
+
+    b = DynamicBatcher(fn, max_batch=8, timeout_ms=200.0, max_queue=64)
+    futs = [b.submit([i, i + 100]) for i in range(4)]  # 8 items: fills one batch without waiting for the timeout
+    t0 = time.monotonic()
+    outs = [f.result(timeout=5) for f in futs]
+    assert time.monotonic() - t0 < 0.19
+    assert calls == [8]
+    for i, o in enumerate(outs):
+        assert o["y"].tolist() == [[2 * i], [2 * (i + 100)]] and o["z"].tolist() == [i, i + 100]
+    # a lone request is released by the timeout; an oversized one is chunked
+    assert b([7])["z"].tolist() == [7]
+    assert b(list(range(20)))["z"].tolist() == list(range(20))
+    assert calls[1:] == [1, 8, 8, 4]
+    st = b.stats()
+    assert st["items"] == 29 and st["batches"] == 5 and st["requests"] == 6
+    # overload: requests beyond the queue bound are rejected, not queued
+    gate = threading.Event()
+    slow = DynamicBatcher(lambda items: (gate.wait(5), {"z": np.array(items)})[1], max_batch=4, timeout_ms=0.0, max_queue=4)
+    first = slow.submit([1])
+    time.sleep(0.05)          # the worker is now blocked inside fn
+    held = slow.submit([2, 3, 4, 5])
+    with pytest.raises(QueueFull):
+        slow.submit([6])
+    gate.set()
+    assert first.result(5)["z"].tolist() == [1] and held.result(5)["z"].tolist() == [2, 3, 4, 5]
+    # an exception inside fn reaches every caller of the batch
+    bad = DynamicBatcher(lambda items: 1 / 0, max_batch=4, timeout_ms=1.0)
+    with pytest.raises(ZeroDivisionError):
+        bad([1])
+    for x in (b, slow, bad):
+        x.close()
+
+
+def test_rest_signatures_match_the_servable(served):
+    server, manager, base, jpegs = served
+    ref = Servable(str(base / "1"), device="cpu").predict_images(jpegs)
+    port = server.port
+    code, status = _call(port, "/v1/models/flowers")
+    assert code == 200 and status["model_version_status"][0] == {
+        "version": "1", "state": "AVAILABLE", "status": {"error_code": "OK", "error_message": ""}}
+    code, meta = _call(port, "/v1/models/flowers/metadata")
+    sigs = meta["metadata"]["signature_def"]["signature_def"]
+    assert sigs["serving_default"]["method_name"] == "tensorflow/serving/classify"
+    assert sigs["predict_images"]["method_name"] == "tensorflow/serving/predict" and meta["metadata"]["classes"] == CLASSES
+    # predict, row format (bare values and named values) and columnar format
+    code, row = _call(port, "/v1/models/flowers:predict", {"instances": [_b64(j) for j in jpegs]})
+    assert code == 200 and len(row["predictions"]) == 6
+    assert [p["classes"] for p in row["predictions"]] == ref["classes"].tolist()
+    assert np.allclose([p["scores"] for p in row["predictions"]], ref["scores"], atol=1e-5)
+    code, named = _call(port, "/v1/models/flowers/versions/1:predict",
+                        {"signature_name": "predict_images", "instances": [{"images": _b64(j)} for j in jpegs[:2]]})
+    assert code == 200 and _same(named["predictions"], row["predictions"][:2])
+    code, col = _call(port, "/v1/models/flowers:predict", {"inputs": {"images": [_b64(j) for j in jpegs[:3]]}})
+    assert code == 200 and col["outputs"]["classes"] == ref["classes"].tolist()[:3]
+    # predict through the classify signature's input: serialized tf.Example
+    code, viaex = _call(port, "/v1/models/flowers:predict",
+                        {"signature_name": "serving_default", "instances": [_b64(example_from_jpeg(jpegs[0]))]})
+    assert code == 200 and _same(viaex["predictions"], row["predictions"][:1])
+    # classify
+    code, cls = _call(port, "/v1/models/flowers:classify", {"examples": [{"image/encoded": _b64(j)} for j in jpegs]})
+    assert code == 200 and [[r[0][0]] for r in cls["results"]] == ref["classes"].tolist()
+    assert np.allclose([[r[0][1]] for r in cls["results"]], ref["scores"], atol=1e-5)
+    # errors
+    assert _call(port, "/v1/models/other:predict", {"instances": []})[0] == 404
+    assert _call(port, "/v1/models/flowers/versions/9:predict", {"instances": [_b64(jpegs[0])]})[0] == 404
+    assert _call(port, "/v1/models/flowers:predict", {"instances": ["not-binary"]})[0] == 400
+    assert _call(port, "/v1/models/flowers:predict", {"instances": [_b64(b"not a jpeg")]})[0] == 400
+    assert _call(port, "/v1/models/flowers:predict", {})[0] == 400
+    assert _call(port, "/v1/models/flowers:classify", {"examples": [{"other": 1}]})[0] == 400
+    code, text = _call(port, "/metrics")
+    assert code == 200 and 'dtfa_http_requests_total{route="predict",code="200"} 4' in text and "dtfa_model_version 1" in text
+    assert _call(port, "/healthz")[0] == 200
+
+
+def test_concurrent_requests_share_batches(served):
+    server, manager, base, jpegs = served
+    results = [None] * 12
+
+    def client(i):
+        results[i] = _call(server.port, "/v1/models/flowers:predict", {"instances": [_b64(jpegs[i % 6])]})
+
+    threads = [threading.Thread(target=client, args=(i,)) for i in range(12)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(r[0] == 200 for r in results)
+    for i in range(6):  # same image -> same answer, whatever batch it rode in
+        assert _same(results[i][1]["predictions"], results[i + 6][1]["predictions"])
+    st = server.batcher.stats()
+    assert st["items"] == 12 and st["batches"] < 12  # merged
+
+
+def test_new_version_is_picked_up_and_broken_one_is_skipped(served):
+    server, manager, base, jpegs = served
+    req = {"instances": [_b64(j) for j in jpegs]}
+    before = _call(server.port, "/v1/models/flowers:predict", req)[1]
+    # an incomplete version directory (no manifest yet) is not a version
+    os.makedirs(base / "2" / "variables")
+    assert list_versions(str(base)) == [1] and not manager.refresh()
+    # a broken export is reported and skipped
+    os.makedirs(base / "3")
+    with open(base / "3" / "saved_model.json", "w") as f:
+        f.write("{}")
+    assert not manager.refresh() and manager.version == 1
+    assert any(s["version"] == "3" and s["state"] == "END" for s in manager.status())
+    # a good newer version replaces the served one
+    _export(base, 4, seed=2)
+    assert manager.refresh() and manager.version == 4
+    after = _call(server.port, "/v1/models/flowers:predict", req)[1]
+    ref = Servable(str(base / "4"), device="cpu").predict_images(jpegs)
+    assert np.allclose([p["scores"] for p in after["predictions"]], ref["scores"], atol=1e-5)
+    assert not np.allclose([p["scores"] for p in before["predictions"]], [p["scores"] for p in after["predictions"]])
+    assert _call(server.port, "/v1/models/flowers/versions/1:predict", req)[0] == 404
+
+
+def test_serve_model_entrypoint(tmp_path):
+    import re
+    import subprocess
+    import sys
+
+    data = _make_dataset(str(tmp_path / "flowers"), n_per_class=2)
+    jpeg = open(sorted(glob.glob(os.path.join(data, "*", "*.jpg")))[0], "rb").read()
+    _export(tmp_path / "models", 7, seed=3)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.Popen([sys.executable, "-u", "serve_model.py", "--model_base_path=%s" % (tmp_path / "models"),
+                             "--model_name=flowers", "--rest_api_port=0", "--device=cpu"],
+                            cwd=os.path.join(root, "recognition_flower", "distributed"), stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, text=True)
+    try:
+        line = proc.stdout.readline()
+        m = re.search(r"version 7 on http://127\.0\.0\.1:(\d+)", line)
+        assert m, line
+        port = int(m.group(1))
+        code, out = _call(port, "/v1/models/flowers:classify", {"examples": [{"image/encoded": _b64(jpeg)}]})
+        assert code == 200 and out["results"][0][0][0] in CLASSES
+    finally:
+        proc.terminate()
+        proc.wait(timeout=20)
