@@ -76,6 +76,25 @@ __device__ __forceinline__ int swz_of_row(int row) {
 // region (at least 4 * (BM/2) * EP_PITCH + BN*8 bytes), free for reuse.  ``valid`` is false for a group
 // that has no tile (it still takes part in the barriers).  Bias / ReLU / batch-norm statistics / bf16 rows
 // staged through LDS so that global stores are 16 B per lane.
+#ifndef CONV_NT
+#define CONV_NT 0
+#endif
+// epilogue traffic hints (CONV_NT: bit 0 = non-temporal output stores, bit 1 = non-temporal operand loads)
+__device__ __forceinline__ void out_store(bf16x8* p, bf16x8 v) {
+#if (CONV_NT & 1)
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ bf16x8 epi_load(const bf16x8* p) {
+#if (CONV_NT & 2)
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 template <int BM, int BN, int EPI>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[BM / 64][BN / 64], char* lds_tiles,
                                               int w4, int lane, int m0, int n0, unsigned tile_m, bool valid) {
@@ -187,7 +206,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
       const size_t off = out_offset(pass, ok);
       if (ok) {
         const int r = pass * RPP + lane / CPR;
-        *(bf16x8*)(p.y + off) = *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16);
+        out_store((bf16x8*)(p.y + off), *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16));
       }
     }
   } else {
@@ -208,11 +227,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
         ooff[i] = out_offset(g0 + i, ook[i]);
         const size_t off = ook[i] ? ooff[i] : 0;  // idle lanes read an in-range dummy
         if (has_add) {
-          addv[i] = *(const bf16x8*)(p.addend + off);
+          addv[i] = epi_load((const bf16x8*)(p.addend + off));
           addm[i] = has_addm ? (unsigned)p.addend_mask[off >> 3] : 0xffu;
         }
         if (EPI == 3) {
-          bnyv[i] = *(const bf16x8*)(p.bn_y + off);
+          bnyv[i] = epi_load((const bf16x8*)(p.bn_y + off));
           bnm[i] = p.bn_relu == 3 ? (unsigned)p.bn_mask[off >> 3] : 0xffu;
         }
       }
@@ -225,7 +244,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (((addm[i] >> j) & 1u) ? (float)addv[i][j] : 0.f));
         }
-        *(bf16x8*)(p.y + ooff[i]) = v;
+        out_store((bf16x8*)(p.y + ooff[i]), v);
         if (EPI == 3) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
