@@ -100,19 +100,24 @@ __device__ __forceinline__ void gather_pool_grad(const bf16* __restrict__ dp, co
   }
 }
 
-// Per-channel partial sums (sum g, sum g*xhat) over a slice of pixels.  Block = TX channel groups x TY
-// pixel lanes, grid = (channel-group blocks, pixel slices); output rows [gridDim.y][2][C].
+// Per-channel partial sums (sum g, sum g*xhat), computed from the pooled side: g is non-zero only at the
+// winning element of a window, so the sums over all full-resolution elements are sums over pooled elements
+// of dp * [relu passed at the winner] * (1, xhat(winner)).  Each thread takes the 8 channels of one pooled
+// pixel, decodes the 8 winning taps and fetches just those 8 values of y (2-byte loads that hit the lines
+// the neighbouring threads touch), instead of every full-resolution element searching its covering windows.
+// Block = TX channel groups x TY pooled-pixel lanes, grid = (channel-group blocks, pixel slices); output
+// rows [gridDim.y][2][C].
 __global__ void bn_pool_bwd_partials_kernel(const bf16* __restrict__ dp, const unsigned char* __restrict__ idx,
                                             const bf16* __restrict__ y, const float* __restrict__ mean,
                                             const float* __restrict__ invstd, const float* __restrict__ scale,
                                             const float* __restrict__ shift, float* __restrict__ out, PoolArgs p,
-                                            int relu, int TX, long long rows_per_block) {
+                                            int relu, int TX, long long rows_per_block, unsigned kw_magic) {
   extern __shared__ float red[];  // [TY][TX][16]
   const int TY = blockDim.x / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int cg = blockIdx.x * TX + tx;
   const int cvec = p.C >> 3;
-  const long long M = (long long)p.B * p.IH * p.IW;
+  const long long M = (long long)p.B * p.OH * p.OW;
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
@@ -128,30 +133,44 @@ __global__ void bn_pool_bwd_partials_kernel(const bf16* __restrict__ dp, const u
     long long r0l = (long long)blockIdx.y * rows_per_block, r1l = r0l + rows_per_block;
     if (r1l > M) r1l = M;
     const unsigned r1 = (unsigned)r1l;  // M < 2^31 (checked by the launcher)
-    constexpr int U = 2;                // pixels per iteration: their loads are all in flight together
+    constexpr int U = 2;                // pooled pixels per iteration: their loads are all in flight together
     for (unsigned r = (unsigned)r0l + ty; r < r1; r += TY * U) {
-      bf16x8 yy[U];
-      float g[U][8];
+      bf16x8 g[U];
+      bf16 yw[U][8];
       bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const unsigned rr = r + u * TY;
         ok[u] = rr < r1;
         const unsigned rc = ok[u] ? rr : r;
-        const unsigned t = rc / (unsigned)p.IW;
-        const int ix = (int)(rc - t * p.IW);
-        const int b = (int)(t / (unsigned)p.IH);
-        const int iy = (int)(t - (unsigned)b * p.IH);
-        yy[u] = *(const bf16x8*)(y + (size_t)rc * p.C + cg * 8);
-        gather_pool_grad(dp, idx, p, b, iy, ix, cg, g[u]);
+        const unsigned t = rc / (unsigned)p.OW;
+        const int ox = (int)(rc - t * p.OW);
+        const int b = (int)(t / (unsigned)p.OH);
+        const int oy = (int)(t - (unsigned)b * p.OH);
+        const size_t o = (size_t)rc * p.C + cg * 8;
+        const uint2 pk = *(const uint2*)(idx + o);
+        g[u] = *(const bf16x8*)(dp + o);
+        const int iy0 = oy * p.sy - p.pt, ix0 = ox * p.sx - p.pl;
+        const bf16* ybase = y + (size_t)b * p.IH * p.IW * p.C + cg * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned tap = ((j < 4 ? pk.x : pk.y) >> (8 * (j & 3))) & 0xff;
+          const unsigned ky = (tap * kw_magic) >> 16;  // tap / kw, exact for tap < 255 and kw <= 16
+          const unsigned kx = tap - ky * p.kw;
+          // the winner always lies inside the image (padding never wins); clamp only guards a corrupt byte
+          int iy = iy0 + (int)ky, ix = ix0 + (int)kx;
+          iy = iy < 0 ? 0 : (iy >= p.IH ? p.IH - 1 : iy);
+          ix = ix < 0 ? 0 : (ix >= p.IW ? p.IW - 1 : ix);
+          yw[u][j] = ybase[((size_t)iy * p.IW + ix) * p.C + j];
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (!ok[u]) continue;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float yf = (float)yy[u][j];
-          float gj = g[u][j];
+          const float yf = (float)yw[u][j];
+          float gj = (float)g[u][j];
           if (relu && !(yf * sc[j] + sh[j] > 0.f)) gj = 0.f;
           s1[j] += gj;
           s2[j] += gj * ((yf - mu[j]) * is[j]);
@@ -223,6 +242,125 @@ __global__ void bn_pool_bwd_apply_kernel(const bf16* __restrict__ dp, const unsi
   }
 }
 
+// Stride-2 fast path of the elementwise backward pass (windows up to 3 x 3): a thread owns the 2 x 2 cell of
+// full-resolution pixels (2a .. 2a+1, 2c .. 2c+1) for 8 channels.  The cell is covered by at most 2 x 2
+// windows, whose pooled gradients and tap bytes are loaded once for the four pixels (the per-pixel search
+// above loads 2.25 windows per pixel and repeats the index arithmetic for each).
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_s2_kernel(
+    const bf16* __restrict__ dp, const unsigned char* __restrict__ idx, const bf16* __restrict__ y,
+    bf16* __restrict__ dy, const float* __restrict__ ca, const float* __restrict__ cb, const float* __restrict__ cc,
+    const float* __restrict__ scale, const float* __restrict__ shift, PoolArgs p, int relu, unsigned ncell) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= ncell) return;
+  const unsigned cvec = (unsigned)p.C >> 3;
+  const unsigned CW = ((unsigned)p.IW + 1) >> 1, CH = ((unsigned)p.IH + 1) >> 1;
+  const unsigned cellpix = i / cvec;
+  const int cg = (int)(i - cellpix * cvec);
+  const unsigned t = cellpix / CW;
+  const int cx = (int)(cellpix - t * CW);
+  const int b = (int)(t / CH);
+  const int cy = (int)(t - (unsigned)b * CH);
+  const int iy0 = cy * 2, ix0 = cx * 2;
+  // first window row / column that can cover the cell: ceil((iy0 + pt - kh + 1) / 2), argument >= -2
+  const int oyb = (iy0 + p.pt - p.kh + 1 + 3) / 2 - 1;
+  const int oxb = (ix0 + p.pl - p.kw + 1 + 3) / 2 - 1;
+
+  // ---- all loads first ----
+  uint2 pk[2][2];
+  bf16x8 gw[2][2];
+  bool wok[2][2];
+#pragma unroll
+  for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+    for (int wx = 0; wx < 2; ++wx) {
+      const int oy = oyb + wy, ox = oxb + wx;
+      // a window takes part if it exists and reaches the cell (a 2 x 2 window reaches only one cell row)
+      wok[wy][wx] = (unsigned)oy < (unsigned)p.OH && (unsigned)ox < (unsigned)p.OW &&
+                    oy * 2 - p.pt <= iy0 + 1 && ox * 2 - p.pl <= ix0 + 1;
+      const size_t o = wok[wy][wx] ? (((size_t)b * p.OH + oy) * p.OW + ox) * p.C + cg * 8 : (size_t)cg * 8;
+      pk[wy][wx] = *(const uint2*)(idx + o);
+      gw[wy][wx] = *(const bf16x8*)(dp + o);
+    }
+  bf16x8 yv[2][2];
+  bool pok[2][2];
+  size_t poff[2][2];
+#pragma unroll
+  for (int py = 0; py < 2; ++py)
+#pragma unroll
+    for (int px = 0; px < 2; ++px) {
+      pok[py][px] = iy0 + py < p.IH && ix0 + px < p.IW;
+      poff[py][px] = pok[py][px] ? (((size_t)b * p.IH + iy0 + py) * p.IW + ix0 + px) * p.C + cg * 8 : (size_t)cg * 8;
+      yv[py][px] = *(const bf16x8*)(y + poff[py][px]);
+    }
+  const int c0 = cg * 8;
+  float A[8], Bc[8], Cc[8], S[8], H[8];
+  {
+    const float4 a0 = *(const float4*)(ca + c0), a1 = *(const float4*)(ca + c0 + 4);
+    const float4 b0 = *(const float4*)(cb + c0), b1 = *(const float4*)(cb + c0 + 4);
+    const float4 d0 = *(const float4*)(cc + c0), d1 = *(const float4*)(cc + c0 + 4);
+    const float4 s0 = *(const float4*)(scale + c0), s1 = *(const float4*)(scale + c0 + 4);
+    const float4 h0 = *(const float4*)(shift + c0), h1 = *(const float4*)(shift + c0 + 4);
+    A[0] = a0.x; A[1] = a0.y; A[2] = a0.z; A[3] = a0.w; A[4] = a1.x; A[5] = a1.y; A[6] = a1.z; A[7] = a1.w;
+    Bc[0] = b0.x; Bc[1] = b0.y; Bc[2] = b0.z; Bc[3] = b0.w; Bc[4] = b1.x; Bc[5] = b1.y; Bc[6] = b1.z; Bc[7] = b1.w;
+    Cc[0] = d0.x; Cc[1] = d0.y; Cc[2] = d0.z; Cc[3] = d0.w; Cc[4] = d1.x; Cc[5] = d1.y; Cc[6] = d1.z; Cc[7] = d1.w;
+    S[0] = s0.x; S[1] = s0.y; S[2] = s0.z; S[3] = s0.w; S[4] = s1.x; S[5] = s1.y; S[6] = s1.z; S[7] = s1.w;
+    H[0] = h0.x; H[1] = h0.y; H[2] = h0.z; H[3] = h0.w; H[4] = h1.x; H[5] = h1.y; H[6] = h1.z; H[7] = h1.w;
+  }
+
+  // ---- route the pooled gradients to the cell's pixels ----
+  float acc[2][2][8];
+#pragma unroll
+  for (int py = 0; py < 2; ++py)
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[py][px][j] = 0.f;
+#pragma unroll
+  for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+    for (int wx = 0; wx < 2; ++wx) {
+      if (!wok[wy][wx]) continue;
+      unsigned tap[8];
+      float g[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        tap[j] = ((j < 4 ? pk[wy][wx].x : pk[wy][wx].y) >> (8 * (j & 3))) & 0xff;
+        g[j] = (float)gw[wy][wx][j];
+      }
+      const int ky0 = iy0 + p.pt - (oyb + wy) * 2, kx0 = ix0 + p.pl - (oxb + wx) * 2;  // tap of cell pixel (0, 0)
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        const int ky = ky0 + py;
+        if ((unsigned)ky >= (unsigned)p.kh) continue;
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          const int kx = kx0 + px;
+          if ((unsigned)kx >= (unsigned)p.kw) continue;
+          const unsigned want = (unsigned)(ky * p.kw + kx);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[py][px][j] += tap[j] == want ? g[j] : 0.f;
+        }
+      }
+    }
+
+  // ---- dy = ca*g + cb*y + cc ----
+#pragma unroll
+  for (int py = 0; py < 2; ++py)
+#pragma unroll
+    for (int px = 0; px < 2; ++px) {
+      if (!pok[py][px]) continue;
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float yf = (float)yv[py][px][j];
+        float gj = acc[py][px][j];
+        if (relu && !(yf * S[j] + H[j] > 0.f)) gj = 0.f;
+        o[j] = (bf16)(A[j] * gj + Bc[j] * yf + Cc[j]);
+      }
+      __builtin_nontemporal_store(o, (bf16x8*)(dy + poff[py][px]));
+    }
+}
+
 static bool pool_args_ok(const PoolArgs* p) {
   return p->C % 8 == 0 && p->kh * p->kw <= 254 && p->kh > 0 && p->kw > 0 && p->sy > 0 && p->sx > 0 && p->B > 0 &&
          p->OH > 0 && p->OW > 0 && (long long)p->B * p->IH * p->IW * (p->C / 8) < (1ll << 31);
@@ -259,7 +397,7 @@ static void partials_geometry(long long M, int C, int* TX, int* gx, int* gy, lon
 extern "C" int dtfa_bn_pool_partials_rows(const PoolArgs* p) {
   int TX, gx, gy;
   long long rpb;
-  partials_geometry((long long)p->B * p->IH * p->IW, p->C, &TX, &gx, &gy, &rpb);
+  partials_geometry((long long)p->B * p->OH * p->OW, p->C, &TX, &gx, &gy, &rpb);
   return gy;
 }
 
@@ -269,10 +407,12 @@ extern "C" int dtfa_bn_pool_bwd_partials(const void* dp, const void* idx, const 
   if (!pool_args_ok(p)) return -1;
   int TX, gx, gy;
   long long rpb;
-  partials_geometry((long long)p->B * p->IH * p->IW, p->C, &TX, &gx, &gy, &rpb);
+  if (p->kw > 16) return -1;
+  partials_geometry((long long)p->B * p->OH * p->OW, p->C, &TX, &gx, &gy, &rpb);
+  const unsigned kw_magic = 65536u / (unsigned)p->kw + 1u;
   hipLaunchKernelGGL(bn_pool_bwd_partials_kernel, dim3(gx, gy), dim3(256), 256 * 16 * sizeof(float), st,
                      (const bf16*)dp, (const unsigned char*)idx, (const bf16*)y, mean, invstd, scale, shift, out, *p,
-                     relu, TX, rpb);
+                     relu, TX, rpb, kw_magic);
   return (int)hipGetLastError();
 }
 
@@ -280,6 +420,14 @@ extern "C" int dtfa_bn_pool_bwd_apply(const void* dp, const void* idx, const voi
                                       const float* cb, const float* cc, const float* scale, const float* shift,
                                       const PoolArgs* p, int relu, hipStream_t st) {
   if (!pool_args_ok(p)) return -1;
+  if (p->sy == 2 && p->sx == 2 && p->kh <= 3 && p->kw <= 3 && p->kh >= 2 && p->kw >= 2 && p->pt >= 0 && p->pt <= 1 &&
+      p->pl >= 0 && p->pl <= 1) {
+    const size_t ncell = (size_t)p->B * ((p->IH + 1) / 2) * ((p->IW + 1) / 2) * (p->C / 8);
+    hipLaunchKernelGGL(bn_pool_bwd_apply_s2_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st,
+                       (const bf16*)dp, (const unsigned char*)idx, (const bf16*)y, (bf16*)dy, ca, cb, cc, scale, shift,
+                       *p, relu, (unsigned)ncell);
+    return (int)hipGetLastError();
+  }
   size_t nvec = (size_t)p->B * p->IH * p->IW * p->C / 8;
   hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(grid_1d(nvec)), dim3(256), 0, st, (const bf16*)dp,
                      (const unsigned char*)idx, (const bf16*)y, (bf16*)dy, ca, cb, cc, scale, shift, *p, relu, nvec);

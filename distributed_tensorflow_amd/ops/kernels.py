@@ -6,6 +6,8 @@ launches on the current stream.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Optional, Tuple
 
@@ -23,14 +25,20 @@ def _as2d(t: torch.Tensor) -> Tuple[int, int]:
 
 
 # ------------------------------------------------------------------ batch norm
-def reduce_partials(part: torch.Tensor, max_rows: int = 64, direct_rows: int = 2048) -> torch.Tensor:
+_REDUCE_ROWS_PER_SPLIT = int(os.environ.get("DTFA_REDUCE_ROWS_PER_SPLIT", "16"))
+
+
+def reduce_partials(part: torch.Tensor, max_rows: int = 1024, direct_rows: int = 2048) -> torch.Tensor:
     """[R][NV][C] -> [RS<=max_rows][NV][C] (fixed summation order).  Up to ``direct_rows`` rows are left
-    alone: the finalize kernels sum that many themselves (32 row lanes), which saves a launch per layer."""
+    alone: the finalize kernels sum that many themselves (32 row lanes), which saves a launch per layer.
+    Above that each output row sums ~16 input rows, so the pass is wide (R/16 x NV*C threads) and short instead
+    of a few long serial chains of dependent loads."""
     R, NV, Cc = part.shape
     if R <= direct_rows:
         return part
-    out = torch.empty((max_rows, NV, Cc), dtype=F32, device=part.device)
-    hipk.check(hipk.lib().dtfa_partial_reduce(part.data_ptr(), out.data_ptr(), R, NV, Cc, max_rows, hipk.stream()),
+    rs = min(max_rows, max(64, -(-R // _REDUCE_ROWS_PER_SPLIT)))
+    out = torch.empty((rs, NV, Cc), dtype=F32, device=part.device)
+    hipk.check(hipk.lib().dtfa_partial_reduce(part.data_ptr(), out.data_ptr(), R, NV, Cc, rs, hipk.stream()),
                "partial_reduce")
     return out
 

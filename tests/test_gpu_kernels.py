@@ -199,6 +199,11 @@ def test_dropout_deterministic_and_unbiased():
     ((2, 17, 19, 24), (3, 3), (2, 2), (1, 1, 1, 1), True),
     ((3, 16, 16, 64), (3, 3), (2, 2), (0, 1, 0, 1), True),
     ((2, 9, 11, 8), (2, 2), (2, 2), (0, 0, 0, 0), False),
+    ((2, 12, 10, 16), (3, 3), (2, 2), (0, 1, 0, 1), True),    # TF SAME on even sizes: padding at the end only
+    ((2, 13, 15, 16), (3, 3), (2, 2), (1, 1, 1, 1), False),   # odd sizes: the last 2 x 2 cell is partial
+    ((1, 8, 8, 8), (2, 2), (2, 2), (1, 1, 1, 1), True),       # 2 x 2 windows that start in the padding
+    ((2, 10, 9, 8), (3, 2), (2, 2), (1, 1, 0, 1), True),      # rectangular window
+    ((2, 9, 9, 8), (3, 3), (1, 1), (1, 1, 1, 1), True),       # stride 1: per-pixel search path
 ])
 def test_bn_relu_maxpool_fused_matches_unfused(shape, k, stride, pads, relu):
     """The fused batch-norm + ReLU + max-pool pair (forward and backward) is bit-identical to the separate
