@@ -70,6 +70,89 @@ __global__ void bn_relu_maxpool_fwd_kernel(const bf16* __restrict__ y, const flo
   }
 }
 
+// ReLU fast path of the forward pass.  After the ReLU every candidate is a non-negative bf16, and those
+// order like 16-bit integers, so the window is reduced two values per instruction: the affine map with
+// v_pk_fma_f32, one rounding (v_cvt_pk_bf16_f32), ReLU and running maximum with v_pk_max_i16.  The winning tap
+// is found afterwards by walking the stored candidates backwards and keeping the tap wherever the candidate
+// equals the maximum (so the first maximum wins, as in the scalar form).  Taps outside the image hold -1,
+// which neither wins nor equals a maximum.
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+typedef short i16x2p __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2p __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_packed_kernel(
+    const bf16* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+    bf16* __restrict__ out, unsigned char* __restrict__ idx, PoolArgs p, unsigned nvec) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= nvec) return;
+  const unsigned cvec = (unsigned)p.C >> 3;
+  const unsigned pix = i / cvec;
+  const int cg = (int)(i - pix * cvec);
+  const unsigned t = pix / (unsigned)p.OW;
+  const int ox = (int)(pix - t * p.OW);
+  const int b = (int)(t / (unsigned)p.OH);
+  const int oy = (int)(t - (unsigned)b * p.OH);
+  const int iy0 = oy * p.sy - p.pt, ix0 = ox * p.sx - p.pl;
+  const bf16* ybase = y + (size_t)b * p.IH * p.IW * p.C + cg * 8;
+  constexpr int NT = KH * KW;
+  u32x4p raw[NT];
+  bool ok[NT];
+#pragma unroll
+  for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) {
+      const int iy = iy0 + ky, ix = ix0 + kx;
+      const int tp = ky * KW + kx;
+      ok[tp] = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      raw[tp] = *(const u32x4p*)(ybase + (ok[tp] ? ((size_t)iy * p.IW + ix) * p.C : 0));
+    }
+  f32x2p sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sc[j] = *(const f32x2p*)(scale + cg * 8 + 2 * j);
+    sh[j] = *(const f32x2p*)(shift + cg * 8 + 2 * j);
+  }
+  const i16x2p zero = {0, 0};
+  unsigned cand[NT][4], best[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int tp = 0; tp < NT; ++tp)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x2p v;
+      v.x = __uint_as_float(raw[tp][j] << 16);
+      v.y = __uint_as_float(raw[tp][j] & 0xffff0000u);
+      const f32x2p f = __builtin_elementwise_fma(v, sc[j], sh[j]);
+      unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2p));
+      w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2p, w), zero));
+      w = ok[tp] ? w : 0xffffffffu;
+      cand[tp][j] = w;
+      best[j] = __builtin_bit_cast(
+          unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2p, best[j]), __builtin_bit_cast(i16x2p, w)));
+    }
+  // winning taps, two 16-bit fields per register
+  unsigned win[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int tp = NT - 1; tp >= 0; --tp)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned x = cand[tp][j] ^ best[j];
+      const unsigned lo = (x & 0xffffu) == 0 ? 0xffffu : 0u, hi = (x >> 16) == 0 ? 0xffff0000u : 0u;
+      const unsigned m = lo | hi;
+      win[j] = (win[j] & ~m) | ((unsigned)tp * 0x00010001u & m);
+    }
+  u32x4p o = {best[0], best[1], best[2], best[3]};
+  *(u32x4p*)(out + (size_t)i * 8) = o;
+  if (idx) {
+    uint2 packed;  // bytes in channel order: fields (lo, hi) of win[0], win[1] | win[2], win[3]
+    packed.x = (win[0] & 0xffu) | ((win[0] >> 8) & 0xff00u) | ((win[1] & 0xffu) << 16) | ((win[1] >> 16) << 24);
+    packed.y = (win[2] & 0xffu) | ((win[2] >> 8) & 0xff00u) | ((win[3] & 0xffu) << 16) | ((win[3] >> 16) << 24);
+    *(uint2*)(idx + (size_t)i * 8) = packed;
+  }
+}
+
 // Pooled gradient routed to full-resolution pixel (b, iy, ix), channels cg*8 .. cg*8+7.
 __device__ __forceinline__ void gather_pool_grad(const bf16* __restrict__ dp, const unsigned char* __restrict__ idx,
                                                  const PoolArgs& p, int b, int iy, int ix, int cg, float acc[8]) {
@@ -375,6 +458,16 @@ extern "C" int dtfa_bn_relu_maxpool_fwd(const void* y, const float* scale, const
                                         const PoolArgs* p, int relu, hipStream_t st) {
   if (!pool_args_ok(p)) return -1;
   size_t nvec = (size_t)p->B * p->OH * p->OW * p->C / 8;
+  if (relu && p->kh == p->kw && (p->kh == 3 || p->kh == 2)) {
+    const dim3 grid((unsigned)((nvec + 255) / 256));
+    if (p->kh == 3)
+      hipLaunchKernelGGL((bn_relu_maxpool_fwd_packed_kernel<3, 3>), grid, dim3(256), 0, st, (const bf16*)y, scale,
+                         shift, (bf16*)out, (unsigned char*)idx, *p, (unsigned)nvec);
+    else
+      hipLaunchKernelGGL((bn_relu_maxpool_fwd_packed_kernel<2, 2>), grid, dim3(256), 0, st, (const bf16*)y, scale,
+                         shift, (bf16*)out, (unsigned char*)idx, *p, (unsigned)nvec);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid_1d(nvec)), dim3(256), 0, st, (const bf16*)y, scale, shift,
                      (bf16*)out, (unsigned char*)idx, *p, relu, nvec);
   return (int)hipGetLastError();
