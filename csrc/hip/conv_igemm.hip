@@ -295,6 +295,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
 #ifndef DTFA_DBG
 #define DTFA_DBG 0
 #endif
+// workgroups per CU the narrow (<= 128 x 64) tiles are compiled for
+#ifndef CONV_NARROW_OCC
+#define CONV_NARROW_OCC 3
+#endif
 
 // WG = 2 doubles the workgroup: 512 threads as two groups of 2 x 2 waves, each group computing its own
 // BM-row tile of a (2 * BM) x BN macro tile against ONE shared BN-column weight tile.  The kernel moves
@@ -302,7 +306,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
 // ~12 TB/s chip-wide with ~90 % L2 hits) is what bounds the compute-heavy layers, and sharing the weight tile
 // takes a quarter of the bytes per FLOP away at 128 x 128.
 template <int BM, int BN, int BK, int EPI, int NST, int WG>
-__global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 : 3))) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 : (BM * BN <= 128 * 64 ? CONV_NARROW_OCC : 3)))) void conv_igemm_kernel(ConvArgs p) {
   constexpr int S = BK / 8;            // 16-byte slots per LDS row
   constexpr int ROWB = BK * 2;         // bytes per LDS row
   constexpr int RPI = 1024 / ROWB;     // rows covered by one wave-instruction
@@ -454,7 +458,13 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 :
   __syncthreads();
 
   bf16x8 af[2][MT], bfr[2][NT];
+#if (DTFA_DBG & 4)
+  bool frag_skip = false;
+#endif
   auto read_frags = [&](int buf, int ks, int dst) {
+#if (DTFA_DBG & 4)
+    if (frag_skip) return;
+#endif
     const char* base = lds_tiles + buf * STAGE;
     const int sl = ks * 2 + khalf;
 #pragma unroll
@@ -506,9 +516,25 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 :
     mfma_step((KS - 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
     cur = nxt;
+#if (DTFA_DBG & 4)
+    frag_skip = true;
+#endif
   }
   __syncthreads();  // all fragment reads done before the tiles are reused by the epilogue
 
+#if (DTFA_DBG & 8)
+  {
+    float sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += acc[mt][nt][j];
+    if (sum == 123.456f) p.y[0] = (bf16)sum;
+    return;
+  }
+#endif
   // each group stages its output through its own part of the (now idle) tile area
   conv_epilogue<BM, BN, EPI>(p, acc, lds_tiles + grp * EP, wid, lane, m0, n0, tile_m, valid);
 }

@@ -215,6 +215,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     M = B * oyn * oxn
     K = T * cin
     bm, bn, bk, nst = pick_fwd_tile(M, cout, K)
+    dense_out = osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow
     L = hipk.lib()
     part = None
     if stats or bn_tap is not None:
@@ -240,7 +241,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     a.T, a.M, a.K = T, M, K
     a.cin_magic = cin_magic
     a.relu = 1 if relu else 0
-    a.dense_out = 1 if (osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow) else 0
+    a.dense_out = 1 if dense_out else 0
     # 1x1 / stride 1 / no padding: input pixel index == output pixel index, the kernel skips the pixel decode
     a.pointwise = 1 if (zero_taps and a.dense_out and T == 1 and isy == 1 and isx == 1
                         and ih == oyn and iw == oxn) else 0

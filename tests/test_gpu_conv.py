@@ -21,6 +21,10 @@ CASES = [
     (1, 35, 35, 48, 64, 5, 5, 1, 1, "SAME"),        # inception 5x5
     (4, 8, 8, 448, 384, 3, 3, 1, 1, "SAME"),
     (5, 12, 12, 32, 40, 3, 3, 2, 2, "SAME"),        # odd Cout tile tail, SAME stride 2
+    (3, 10, 12, 32, 128, 3, 3, 1, 1, "SAME"),       # halo kernel: one 32-channel chunk, tiles span images
+    (2, 28, 28, 128, 128, 3, 3, 1, 1, "SAME"),      # halo kernel: resnet 3x3, four chunks
+    (1, 57, 57, 64, 72, 3, 3, 1, 1, "SAME"),        # halo kernel: wide rows (244-pixel image), Cout tail
+    (2, 20, 20, 96, 64, 3, 1, 1, 1, "SAME"),        # halo kernel: 3 taps, narrow output tile
 ]
 
 
@@ -124,7 +128,8 @@ def test_dgrad_masked_addend():
 
 
 @pytest.mark.parametrize("relu_mode", [0, 2, 3])
-@pytest.mark.parametrize("case", [(2, 14, 14, 64, 32, 1, 1, 1, 1, "VALID"), (3, 9, 11, 40, 72, 3, 3, 1, 1, "SAME")])
+@pytest.mark.parametrize("case", [(2, 14, 14, 64, 32, 1, 1, 1, 1, "VALID"), (3, 9, 11, 40, 72, 3, 3, 1, 1, "SAME"),
+                                  (2, 12, 12, 64, 64, 3, 3, 1, 1, "SAME")])
 def test_dgrad_emits_bn_backward_partials(case, relu_mode):
     """A data-gradient launch can emit (sum g, sum g*xhat) of the batch-norm layer below it; the sums equal
     those of the gradient tensor it wrote."""
