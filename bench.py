@@ -33,7 +33,7 @@ from distributed_tensorflow_amd.parallel.engine import DataParallelEngine  # noq
 
 # per-GPU batches sized for 288 GB of HBM: ResNet-50 at 1024 holds ~40 GB of activations and runs ~13 % more
 # images/s than at 256 (fixed per-layer costs and tile-quantisation tails amortise)
-DEFAULT_BATCH = {"resnet50": 1024, "flower_cnn": 1024, "inception_v3_head": 256}
+DEFAULT_BATCH = {"resnet50": 2048, "flower_cnn": 1024, "inception_v3_head": 256}
 IMAGE_SIZE = {"resnet50": 224, "flower_cnn": 224, "inception_v3_head": 299}
 
 
