@@ -339,7 +339,10 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 :
   const bool valid = tile_m < mtiles;   // the last macro tile may have a group without rows
   const int m0 = valid ? (int)(tile_m * BM) : p.M, n0 = tile_n * BN;
 
-  if (tid < p.T) lds_taps[tid] = p.taps[tid];
+  // (a pointwise convolution never looks at the tap table: its workgroups skip this global round trip and
+  // the barrier that publishes it)
+  const bool pointwise = p.pointwise != 0;
+  if (!pointwise && tid < p.T) lds_taps[tid] = p.taps[tid];
 
   // ---- per-thread staging rows (fixed across the K loop) ----
   const int slot = lane % S;
@@ -350,7 +353,6 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 :
   int aiy[NA], aix[NA];
   const int opix = p.OYn * p.OXn;
   // 1x1 / stride-1 / unpadded: input pixel == output pixel == m, no decode and no bounds checks
-  const bool pointwise = p.pointwise != 0;
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     int m = m0 + (i * 4 + wid) * RPI + row_in_inst;
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 :
     bbase[i] = p.w + (size_t)(bok[i] ? n : 0) * p.K;
   }
 
-  __syncthreads();  // tap table visible
+  if (!pointwise) __syncthreads();  // tap table visible
 
   auto stage = [&](int kt, int buf) {
     char* sa = lds_tiles + buf * STAGE + grp * (BM * ROWB);
