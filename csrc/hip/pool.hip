@@ -131,6 +131,59 @@ __global__ void avgpool_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict_
   }
 }
 
+// Fixed-window form: one output vector per thread, 32-bit index arithmetic, every tap's load requested before
+// the first is consumed, two fp32 sums per instruction (v_pk_add_f32).  Taps are added in the same (ky, kx)
+// order as the generic kernel, so the results are identical.
+typedef float pool_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int pool_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pool_bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void avgpool_fwd_fixed_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                                PoolArgs p, unsigned nvec) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= nvec) return;
+  const unsigned cvec = (unsigned)p.C >> 3;
+  const unsigned pix = i / cvec;
+  const int cg = (int)(i - pix * cvec);
+  const unsigned t = pix / (unsigned)p.OW;
+  const int ox = (int)(pix - t * p.OW);
+  const int b = (int)(t / (unsigned)p.OH);
+  const int oy = (int)(t - (unsigned)b * p.OH);
+  const int iy0 = oy * p.sy - p.pt, ix0 = ox * p.sx - p.pl;
+  const bf16* base = x + (size_t)b * p.IH * p.IW * p.C + cg * 8;
+  pool_u32x4 v[KH * KW];
+  bool ok[KH * KW];
+#pragma unroll
+  for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) {
+      const int iy = iy0 + ky, ix = ix0 + kx;
+      ok[ky * KW + kx] = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      v[ky * KW + kx] = *(const pool_u32x4*)(base + (ok[ky * KW + kx] ? ((size_t)iy * p.IW + ix) * p.C : 0));
+    }
+  pool_f32x2 acc[4] = {};
+  int cnt = 0;
+#pragma unroll
+  for (int tp = 0; tp < KH * KW; ++tp) {
+    if (!ok[tp]) continue;
+    ++cnt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pool_f32x2 f;
+      f.x = __uint_as_float(v[tp][j] << 16);
+      f.y = __uint_as_float(v[tp][j] & 0xffff0000u);
+      acc[j] += f;
+    }
+  }
+  const float inv = 1.f / (float)(p.count_include_pad ? KH * KW : (cnt > 0 ? cnt : 1));
+  pool_u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    o[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(acc[j] * inv, pool_bf16x2));
+  *(pool_u32x4*)(y + (size_t)i * 8) = o;
+}
+
 __device__ __forceinline__ int window_count(int o, int s, int k, int pad, int n) {
   int lo = o * s - pad, hi = lo + k;
   if (lo < 0) lo = 0;
@@ -237,6 +290,11 @@ extern "C" int dtfa_avgpool_fwd(const void* x, void* y, const PoolArgs* p, hipSt
   if (p->C % 8) return -1;
   size_t nvec = (size_t)p->B * p->OH * p->OW * p->C / 8;
   if (!nvec) return 0;
+  if (p->kh == 3 && p->kw == 3 && nvec < (1ull << 31)) {
+    hipLaunchKernelGGL((avgpool_fwd_fixed_kernel<3, 3>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st,
+                       (const bf16*)x, (bf16*)y, *p, (unsigned)nvec);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, *p, nvec);
   return (int)hipGetLastError();
 }
