@@ -80,11 +80,11 @@ def main():
     engine = DataParallelEngine(model, mode=args.mode, optimizer=opt, lr=lr, opt_kwargs=okw,
                                 bucket_mb=args.bucket_mb, staleness=args.staleness, p2p_max_bytes=args.p2p_kb * 1024)
 
-    g = torch.Generator(device="cpu").manual_seed(rank)
-    images = torch.zeros(batch, size, size, 8)
-    images[..., :3] = torch.rand(batch, size, size, 3, generator=g) * 2 - 1
-    images = images.to(device=device, dtype=torch.bfloat16)
-    labels = torch.randint(0, 5, (batch,), generator=g).to(device=device, dtype=torch.int32)
+    # synthetic batch generated on the device (a 2048 x 224 x 224 host tensor per rank would cost seconds and GBs)
+    g = torch.Generator(device=device).manual_seed(1000 + rank)
+    images = torch.zeros(batch, size, size, 8, device=device, dtype=torch.bfloat16)
+    images[..., :3] = (torch.rand(batch, size, size, 3, device=device, generator=g) * 2 - 1).to(torch.bfloat16)
+    labels = torch.randint(0, 5, (batch,), device=device, generator=g).to(torch.int32)
 
     def step():
         engine.begin_step()
