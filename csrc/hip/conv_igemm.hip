@@ -463,7 +463,12 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 :
 #if (DTFA_DBG & 4)
   bool frag_skip = false;
 #endif
+  // A wave whose 32/64 output columns all lie beyond Cout (a 64-wide tile on a 32-channel output, the
+  // 32-column tail of 160 channels) takes part in the loads and barriers but skips its fragment reads and
+  // MFMAs, leaving its SIMD's matrix pipe to the other workgroups on the CU.
+  const bool wave_live = n0 + wc * WN < p.Cout;
   auto read_frags = [&](int buf, int ks, int dst) {
+    if (!wave_live) return;
 #if (DTFA_DBG & 4)
     if (frag_skip) return;
 #endif
@@ -475,6 +480,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 :
     for (int nt = 0; nt < NT; ++nt) bfr[dst][nt] = *(const bf16x8*)(base + boff[nt] + ((sl ^ bswz[nt]) << 4));
   };
   auto mfma_step = [&](int src) {
+    if (!wave_live) return;
 #if (DTFA_DBG & 2)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
