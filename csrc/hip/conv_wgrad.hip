@@ -325,6 +325,8 @@ extern "C" int dtfa_conv_wgrad(WgradArgs* a, int bmw, int bnw, int bkp, int spli
   CASE(64, 64, 32)
   CASE(128, 128, 64)
   CASE(64, 128, 64)
+  CASE(128, 64, 64)
+  CASE(64, 64, 64)
 #undef CASE
   return -3;
 }

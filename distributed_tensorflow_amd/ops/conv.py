@@ -195,7 +195,10 @@ def pick_wgrad_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
     forced = _env_tile("DTFA_WGRAD_TILE")
     bmw = 128 if cout > 64 else 64
     bnw = 128 if (K > 64 and cout > 64) else 64  # narrow outputs: 64x64 tiles won every such shape in the sweep
-    bkp = 32
+    # a small output over very many pixels with a 128-wide X tile (the 56x56 256->64 / 256->128 1x1 layers at
+    # large batch) is bound by streaming dY and X: a 64-pixel k-step halves the barriers per byte moved
+    # (+4 .. 10 % there); everywhere else 32 pixels with three stages measured faster
+    bkp = 64 if (128 <= K <= 256 and cout <= 128 and M >= 1 << 20) else 32
     if forced:
         bmw, bnw, bkp = forced[:3]
     tiles = -(-cout // bmw) * -(-K // bnw)
