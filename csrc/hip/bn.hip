@@ -70,16 +70,25 @@ __device__ inline bool reduce_part_rows(const float* __restrict__ part, int R, i
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
   if (c < C) {
+    // the kernel is a chain of dependent-latency loads: keep eight in flight per thread
     int r = ty;
-    for (; r + RL < R; r += 2 * RL) {
-      float p0 = part[((size_t)r * 2) * C + c], q0 = part[((size_t)r * 2 + 1) * C + c];
-      float p1 = part[((size_t)(r + RL) * 2) * C + c], q1 = part[((size_t)(r + RL) * 2 + 1) * C + c];
-      a0 += (double)p0;
-      b0 += (double)q0;
-      a1 += (double)p1;
-      b1 += (double)q1;
+    for (; r + 3 * RL < R; r += 4 * RL) {
+      float p[4], q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p[u] = part[((size_t)(r + u * RL) * 2) * C + c];
+        q[u] = part[((size_t)(r + u * RL) * 2 + 1) * C + c];
+      }
+      a0 += (double)p[0];
+      b0 += (double)q[0];
+      a1 += (double)p[1];
+      b1 += (double)q[1];
+      a0 += (double)p[2];
+      b0 += (double)q[2];
+      a1 += (double)p[3];
+      b1 += (double)q[3];
     }
-    if (r < R) {
+    for (; r < R; r += RL) {
       a0 += (double)part[((size_t)r * 2) * C + c];
       b0 += (double)part[((size_t)r * 2 + 1) * C + c];
     }
