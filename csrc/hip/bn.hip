@@ -335,18 +335,21 @@ __global__ void col_partials_kernel(const bf16* __restrict__ a, const bf16* __re
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int cg = blockIdx.x * TX + tx;
   const int cvec = C >> 3;
-  float s1[8], s2[8];
+  // sums kept as fp32 pairs (two channels per register pair): the loop body is v_pk_fma_f32 / v_pk_add_f32
+  f32x2 s1p[4], s2p[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  for (int j = 0; j < 4; ++j) s1p[j] = s2p[j] = f32x2{0.f, 0.f};
   if (cg < cvec) {
-    float mu[8], is[8], sc[8], sh[8];
+    // xhat = y * is + xc with xc = -mean * is
+    f32x2 is2[4], xc2[4], sc2[4], sh2[4];
     if (MODE == 1) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        mu[j] = mean[cg * 8 + j];
-        is[j] = invstd[cg * 8 + j];
-        sc[j] = relu == 2 ? scale[cg * 8 + j] : 0.f;
-        sh[j] = relu == 2 ? shift[cg * 8 + j] : 0.f;
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 mu = *(const f32x2*)(mean + cg * 8 + 2 * j);
+        is2[j] = *(const f32x2*)(invstd + cg * 8 + 2 * j);
+        xc2[j] = -mu * is2[j];
+        sc2[j] = relu == 2 ? *(const f32x2*)(scale + cg * 8 + 2 * j) : f32x2{0.f, 0.f};
+        sh2[j] = relu == 2 ? *(const f32x2*)(shift + cg * 8 + 2 * j) : f32x2{0.f, 0.f};
       }
     }
     long long r0 = (long long)blockIdx.y * rows_per_block;
@@ -355,7 +358,7 @@ __global__ void col_partials_kernel(const bf16* __restrict__ a, const bf16* __re
     // U rows per iteration: all loads of an iteration are issued before any of them is consumed
     constexpr int U = 4;
     for (long long r = r0 + ty; r < r1; r += (long long)TY * U) {
-      bf16x8 v[U], yy[U], zz[U];
+      u32x4 v[U], yy[U], zz[U];
       unsigned mb[U];
       bool ok[U];
 #pragma unroll
@@ -363,43 +366,51 @@ __global__ void col_partials_kernel(const bf16* __restrict__ a, const bf16* __re
         long long rr = r + (long long)u * TY;
         ok[u] = rr < r1;
         size_t off = (size_t)(ok[u] ? rr : r) * C + (size_t)cg * 8;
-#if (BN_NT & 4)
-        v[u] = __builtin_nontemporal_load((const bf16x8*)(a + off));
-        if (MODE == 1) yy[u] = __builtin_nontemporal_load((const bf16x8*)(yv + off));
-#else
-        v[u] = *(const bf16x8*)(a + off);
-        if (MODE == 1) yy[u] = *(const bf16x8*)(yv + off);
-#endif
+        v[u] = *(const u32x4*)(a + off);
         if (MODE == 1) {
-          if (relu == 1) zz[u] = *(const bf16x8*)(zout + off);
+          yy[u] = *(const u32x4*)(yv + off);
+          if (relu == 1) zz[u] = *(const u32x4*)(zout + off);
           if (relu == 3) mb[u] = ((const unsigned char*)zout)[off >> 3];
         }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (!ok[u]) continue;
-        if (MODE == 0) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float f = (float)v[u][j];
-            s1[j] += f;
-            s2[j] += f * f;
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float g = (float)v[u][j];
-            float yf = (float)yy[u][j];
-            if (relu == 1 && !((float)zz[u][j] > 0.f)) g = 0.f;
-            if (relu == 2 && !(yf * sc[j] + sh[j] > 0.f)) g = 0.f;
-            if (relu == 3 && !((mb[u] >> j) & 1u)) g = 0.f;
-            float xh = (yf - mu[j]) * is[j];
-            s1[j] += g;
-            s2[j] += g * xh;
+        for (int j = 0; j < 4; ++j) {
+          if (MODE == 0) {
+            const f32x2 f = unpack_bf16x2(v[u][j]);
+            s1p[j] += f;
+            s2p[j] = __builtin_elementwise_fma(f, f, s2p[j]);
+          } else {
+            const f32x2 yf = unpack_bf16x2(yy[u][j]);
+            unsigned gw = v[u][j];
+            if (relu == 1) {
+              const unsigned zw = zz[u][j];  // z >= 0 after the ReLU: clipped <=> the half is zero
+              gw &= ((zw & 0xffffu) != 0 ? 0xffffu : 0u) | ((zw >> 16) != 0 ? 0xffff0000u : 0u);
+            } else if (relu == 2) {
+              const f32x2 pre = __builtin_elementwise_fma(yf, sc2[j], sh2[j]);
+              gw &= (pre.x > 0.f ? 0xffffu : 0u) | (pre.y > 0.f ? 0xffff0000u : 0u);
+            } else if (relu == 3) {
+              const unsigned m2 = mb[u] >> (2 * j);
+              gw &= ((m2 & 1u) ? 0xffffu : 0u) | ((m2 & 2u) ? 0xffff0000u : 0u);
+            }
+            const f32x2 g = unpack_bf16x2(gw);
+            const f32x2 xh = __builtin_elementwise_fma(yf, is2[j], xc2[j]);
+            s1p[j] += g;
+            s2p[j] = __builtin_elementwise_fma(g, xh, s2p[j]);
           }
         }
       }
     }
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s1[2 * j] = s1p[j].x;
+    s1[2 * j + 1] = s1p[j].y;
+    s2[2 * j] = s2p[j].x;
+    s2[2 * j + 1] = s2p[j].y;
   }
   float* mine = red + ((size_t)ty * TX + tx) * 16;
 #pragma unroll
