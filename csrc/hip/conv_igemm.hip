@@ -295,6 +295,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
 #ifndef DTFA_DBG
 #define DTFA_DBG 0
 #endif
+// main-loop order: 0 = fragment reads of k-step ks+1, then the MFMAs of ks; 1 = MFMAs first, reads behind the
+// group; 2 = one read behind each MFMA of the group
+#ifndef CONV_INTERLEAVE
+#define CONV_INTERLEAVE 2
+#endif
 // workgroups per CU the narrow (<= 128 x 64) tiles are compiled for
 #ifndef CONV_NARROW_OCC
 #define CONV_NARROW_OCC 3
@@ -497,6 +502,41 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 :
 #endif
   };
 
+  // MFMAs of fragment set ``src`` with the reads of (buf, ks) into set ``dst`` issued one behind each MFMA
+  auto mfma_read_step = [&](int src, int buf, int ks, int dst, bool do_read) {
+    if (!wave_live) return;
+#if (DTFA_DBG & 6)
+    mfma_step(src);
+    if (do_read) read_frags(buf, ks, dst);
+#else
+    const char* base = lds_tiles + buf * STAGE;
+    const int sl = ks * 2 + khalf;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[src][mt], bfr[src][nt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int i = mt * NT + nt;
+        if (do_read) {
+          if (i < MT) af[dst][i] = *(const bf16x8*)(base + aoff[i] + ((sl ^ aswz[i]) << 4));
+          else if (i < MT + NT) bfr[dst][i - MT] = *(const bf16x8*)(base + boff[i - MT] + ((sl ^ bswz[i - MT]) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    // tiles with fewer MFMAs than fragments (a single MFMA per k-step): the remaining reads
+    if (do_read) {
+#pragma unroll
+      for (int i = MT * NT; i < MT + NT; ++i) {
+        if (i < MT) af[dst][i] = *(const bf16x8*)(base + aoff[i] + ((sl ^ aswz[i]) << 4));
+        else bfr[dst][i - MT] = *(const bf16x8*)(base + boff[i - MT] + ((sl ^ bswz[i - MT]) << 4));
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+
   read_frags(0, 0, 0);
   int cur = 0;  // kt % NST
   for (int kt = 0; kt < KT; ++kt) {
@@ -505,11 +545,26 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 :
     if (kt + NST - 1 < KT && !(DTFA_DBG & 1)) stage(kt + NST - 1, NST == 2 ? nxt : (nxt == 2 ? 0 : nxt + 1));
 #pragma unroll
     for (int ks = 0; ks + 1 < KS; ++ks) {
+#if CONV_INTERLEAVE
+      // MFMAs of k-step ks first, then the LDS reads of k-step ks+1, which complete in the shadow of those
+      // MFMAs: an MFMA group waits only for fragments requested a whole k-step earlier.  With the reads issued
+      // BEFORE the MFMAs, the compiler's lgkmcnt(0) in front of the group waited for the fresh reads as well.
+#if CONV_INTERLEAVE == 2
+      mfma_read_step(ks & 1, cur, ks + 1, (ks + 1) & 1, true);
+      __builtin_amdgcn_sched_barrier(0);
+#else
+      mfma_step(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(cur, ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#else
       read_frags(cur, ks + 1, (ks + 1) & 1);
       // keep the reads ahead of the MFMAs: left alone the scheduler sinks them and reuses one register set
       __builtin_amdgcn_sched_barrier(0);
       mfma_step(ks & 1);
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     if (kt + 1 < KT) {
       // this wave's reads of tile kt are complete and everything but the stage just requested has landed;
@@ -518,11 +573,23 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 :
       if (NST == 3 && kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+#if !CONV_INTERLEAVE
       read_frags(nxt, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
+#if CONV_INTERLEAVE == 2
+    mfma_read_step((KS - 1) & 1, nxt, 0, 0, kt + 1 < KT);
+    __builtin_amdgcn_sched_barrier(0);
+#else
     mfma_step((KS - 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
+#if CONV_INTERLEAVE
+    // the first fragments of tile kt+1, requested in the shadow of the MFMAs just issued
+    if (kt + 1 < KT) read_frags(nxt, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
     cur = nxt;
 #if (DTFA_DBG & 4)
     frag_skip = true;

@@ -44,6 +44,10 @@ __device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)p);
 }
 
+#ifndef WGRAD_MFMA_FIRST
+#define WGRAD_MFMA_FIRST 0
+#endif
+
 template <int BMW, int BNW, int BKP>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int RBA = BMW * 2, RBB = BNW * 2;       // row bytes
@@ -216,20 +220,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       if (kt + NST - 1 < kt_end) stage(kt + NST - 1, NST == 2 ? nxt : (nxt == 2 ? 0 : nxt + 1));
 #pragma unroll
       for (int ks = 0; ks + 1 < KS; ++ks) {
+#if WGRAD_MFMA_FIRST
+        // MFMAs of k-step ks, then the reads of ks+1 in their shadow (an MFMA group then waits only for
+        // fragments requested a whole k-step earlier)
+        mfma_step(ks & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(cur, ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#else
         load_frags(cur, ks + 1, (ks + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs
         mfma_step(ks & 1);
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       if (kt + 1 < kt_end) {
         if (NST == 3 && kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#if !WGRAD_MFMA_FIRST
         load_frags(nxt, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       mfma_step((KS - 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
+#if WGRAD_MFMA_FIRST
+      if (kt + 1 < kt_end) load_frags(nxt, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       cur = nxt;
     }
   }
