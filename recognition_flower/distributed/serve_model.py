@@ -11,6 +11,9 @@ external model server.  This entry point is that server::
     curl -d '{"instances": [{"b64": "'$(base64 -w0 rose.jpg)'"}]}' localhost:8501/v1/models/flowers:predict
     curl -d '{"examples": [{"image/encoded": {"b64": "'$(base64 -w0 rose.jpg)'"}}]}' localhost:8501/v1/models/flowers:classify
 
+gRPC clients reach ``tensorflow.serving.PredictionService`` (Predict, Classify) and
+``tensorflow.serving.ModelService`` (GetModelStatus) on ``--port``.
+
 The newest integer-named version under ``--model_base_path`` is served and the
 directory is polled for newer ones.  Concurrent requests are merged into GPU
 batches of up to ``--max_batch_size`` images (``--batch_timeout_ms`` bounds the
@@ -26,6 +29,7 @@ from distributed_tensorflow_amd.utils import flags  # noqa: E402
 flags.DEFINE_string("model_base_path", "./output/models", "Directory holding <version>/ servable exports.")
 flags.DEFINE_string("model_name", "flowers", "Name in the request path /v1/models/<name>.")
 flags.DEFINE_integer("rest_api_port", 8501, "HTTP port (0 picks a free one).")
+flags.DEFINE_integer("port", 8500, "gRPC port of PredictionService / ModelService (-1 disables gRPC, 0 picks a free one).")
 flags.DEFINE_string("host", "127.0.0.1", "Interface to bind.")
 flags.DEFINE_integer("max_batch_size", 64, "Largest number of images merged into one forward pass.")
 flags.DEFINE_float("batch_timeout_ms", 2.0, "Longest wait for a batch to fill.")
@@ -54,13 +58,21 @@ def main(argv):
         wait_for_version(manager, FLAGS.wait_for_model_seconds)
     server = ModelServer(manager, FLAGS.host, FLAGS.rest_api_port, max_batch=FLAGS.max_batch_size,
                          batch_timeout_ms=FLAGS.batch_timeout_ms, max_queue=FLAGS.max_enqueued_images)
-    print("serving model %r version %s on http://%s:%d (device %s)"
-          % (FLAGS.model_name, manager.version, FLAGS.host, server.port, device), flush=True)
+    grpc_server = None
+    if FLAGS.port >= 0:
+        from distributed_tensorflow_amd.serving import GrpcModelServer
+
+        grpc_server = GrpcModelServer(manager, server.batcher, FLAGS.host, FLAGS.port).start()
+    print("serving model %r version %s on http://%s:%d%s (device %s)"
+          % (FLAGS.model_name, manager.version, FLAGS.host, server.port,
+             " and grpc://%s:%d" % (FLAGS.host, grpc_server.port) if grpc_server else "", device), flush=True)
     try:
         server.serve_forever()
     except KeyboardInterrupt:
         pass
     finally:
+        if grpc_server is not None:
+            grpc_server.stop()
         server.stop()
     return 0
 

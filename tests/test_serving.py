@@ -192,12 +192,12 @@ def test_serve_model_entrypoint(tmp_path):
     _export(tmp_path / "models", 7, seed=3)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     proc = subprocess.Popen([sys.executable, "-u", "serve_model.py", "--model_base_path=%s" % (tmp_path / "models"),
-                             "--model_name=flowers", "--rest_api_port=0", "--device=cpu"],
+                             "--model_name=flowers", "--rest_api_port=0", "--port=0", "--device=cpu"],
                             cwd=os.path.join(root, "recognition_flower", "distributed"), stdout=subprocess.PIPE,
                             stderr=subprocess.STDOUT, text=True)
     try:
         line = proc.stdout.readline()
-        m = re.search(r"version 7 on http://127\.0\.0\.1:(\d+)", line)
+        m = re.search(r"version 7 on http://127\.0\.0\.1:(\d+) and grpc://127\.0\.0\.1:(\d+)", line)
         assert m, line
         port = int(m.group(1))
         code, out = _call(port, "/v1/models/flowers:classify", {"examples": [{"image/encoded": _b64(jpeg)}]})
@@ -205,3 +205,106 @@ def test_serve_model_entrypoint(tmp_path):
     finally:
         proc.terminate()
         proc.wait(timeout=20)
+
+
+def test_grpc_prediction_service(served):
+    """Predict / Classify / GetModelStatus over gRPC agree with the servable and with the REST front end."""
+    import grpc
+
+    from distributed_tensorflow_amd.serving import GrpcModelServer
+    from distributed_tensorflow_amd.serving import tfs_proto as P
+
+    server, manager, base, jpegs = served
+    ref = Servable(str(base / "1"), device="cpu").predict_images(jpegs)
+    g = GrpcModelServer(manager, server.batcher, port=0).start()
+    try:
+        ch = grpc.insecure_channel("127.0.0.1:%d" % g.port)
+        predict = ch.unary_unary("/tensorflow.serving.PredictionService/Predict",
+                                 request_serializer=P.PredictRequest.SerializeToString,
+                                 response_deserializer=P.PredictResponse.FromString)
+        classify = ch.unary_unary("/tensorflow.serving.PredictionService/Classify",
+                                  request_serializer=P.ClassificationRequest.SerializeToString,
+                                  response_deserializer=P.ClassificationResponse.FromString)
+        status = ch.unary_unary("/tensorflow.serving.ModelService/GetModelStatus",
+                                request_serializer=P.GetModelStatusRequest.SerializeToString,
+                                response_deserializer=P.GetModelStatusResponse.FromString)
+        # Predict, predict_images signature
+        req = P.PredictRequest()
+        req.model_spec.name, req.model_spec.signature_name = "flowers", "predict_images"
+        req.inputs["images"].CopyFrom(P.string_tensor(jpegs))
+        resp = predict(req, timeout=60)
+        assert resp.model_spec.name == "flowers" and resp.model_spec.version.value == 1
+        assert set(resp.outputs) == {"classes", "scores"}
+        assert [d.size for d in resp.outputs["classes"].tensor_shape.dim] == [6, 1] and resp.outputs["classes"].dtype == P.DT_STRING
+        assert [[v.decode()] for v in resp.outputs["classes"].string_val] == ref["classes"].tolist()
+        assert resp.outputs["scores"].dtype == P.DT_FLOAT
+        assert np.allclose(np.array(resp.outputs["scores"].float_val).reshape(6, 1), ref["scores"], atol=1e-5)
+        # Predict through the classify signature's input (serialized tf.Example), with an output filter
+        req2 = P.PredictRequest()
+        req2.model_spec.name, req2.model_spec.signature_name = "flowers", "serving_default"
+        req2.inputs["inputs"].CopyFrom(P.string_tensor([example_from_jpeg(j) for j in jpegs[:2]]))
+        req2.output_filter.append("scores")
+        resp2 = predict(req2, timeout=60)
+        assert set(resp2.outputs) == {"scores"}
+        assert np.allclose(np.array(resp2.outputs["scores"].float_val).reshape(2, 1), ref["scores"][:2], atol=1e-5)
+        # Classify
+        creq = P.ClassificationRequest()
+        creq.model_spec.name = "flowers"
+        for j in jpegs:
+            creq.input.example_list.examples.add().features.feature["image/encoded"].bytes_list.value.append(j)
+        cresp = classify(creq, timeout=60)
+        got = [(c.classes[0].label, c.classes[0].score) for c in cresp.result.classifications]
+        assert [[l] for l, _ in got] == ref["classes"].tolist()
+        assert np.allclose([[s] for _, s in got], ref["scores"], atol=1e-5)
+        # the same answer as the REST front end
+        rest = _call(server.port, "/v1/models/flowers:classify", {"examples": [{"image/encoded": _b64(j)} for j in jpegs]})[1]
+        assert [r[0][0] for r in rest["results"]] == [l for l, _ in got]
+        # status
+        sreq = P.GetModelStatusRequest()
+        sreq.model_spec.name = "flowers"
+        st = status(sreq, timeout=30)
+        assert [(m.version, m.state) for m in st.model_version_status] == [(1, 30)]
+        # errors carry gRPC status codes
+        bad = P.PredictRequest()
+        bad.model_spec.name = "other"
+        bad.inputs["images"].CopyFrom(P.string_tensor(jpegs[:1]))
+        with pytest.raises(grpc.RpcError) as e:
+            predict(bad, timeout=30)
+        assert e.value.code() == grpc.StatusCode.NOT_FOUND
+        req.model_spec.version.value = 9
+        with pytest.raises(grpc.RpcError) as e:
+            predict(req, timeout=30)
+        assert e.value.code() == grpc.StatusCode.NOT_FOUND
+        junk = P.PredictRequest()
+        junk.inputs["images"].CopyFrom(P.string_tensor([b"not a jpeg"]))
+        with pytest.raises(grpc.RpcError) as e:
+            predict(junk, timeout=30)
+        assert e.value.code() == grpc.StatusCode.INVALID_ARGUMENT
+        ch.close()
+    finally:
+        g.stop()
+
+
+def test_tfs_proto_wire_bytes():
+    """The declared messages serialise to the wire bytes the protobuf encoding rules give for the published
+    field numbers (hand-assembled below), and tf.Example matches the native encoder used for TFRecords."""
+    from distributed_tensorflow_amd.io.tfrecord import make_example
+    from distributed_tensorflow_amd.serving import tfs_proto as P
+
+    r = P.PredictRequest()
+    r.model_spec.name, r.model_spec.signature_name = "m", "s"
+    r.model_spec.version.value = 3
+    r.inputs["images"].CopyFrom(P.string_tensor([b"ab"]))
+    want = bytes.fromhex(
+        "0a0a" "0a016d" "12020803" "1a0173"                    # 1: ModelSpec{1:"m", 2:Int64Value{1:3}, 3:"s"}
+        "1216" "0a06696d61676573" "120c" "0807" "12041202" "0801" "42026162")  # 2: {"images": TensorProto{...}}
+    assert r.SerializeToString() == want
+    t = P.float_tensor([1.0, 2.0], [2, 1])
+    assert t.SerializeToString() == bytes.fromhex("0801" "1208" "12020802" "12020801" "2a08" "0000803f" "00000040")
+    c = P.ClassificationResponse()
+    one = c.result.classifications.add().classes.add()
+    one.label, one.score = "x", 1.0
+    assert c.SerializeToString() == bytes.fromhex("0a0c" "0a0a" "0a08" "0a0178" "150000803f")
+    ex = P.Example()
+    ex.features.feature["image/encoded"].bytes_list.value.append(b"JPEG")
+    assert ex.SerializeToString() == make_example({"image/encoded": b"JPEG"})
