@@ -37,16 +37,38 @@ class ClusterSpec:
         return self.jobs.get("worker", [])
 
     @property
+    def chief_hosts(self) -> List[str]:
+        """A dedicated chief replica (job ``chief``, or ``master`` in older operators), as Kubeflow's TFJob
+        writes it; the reference's own clusters have none and use worker 0."""
+        return self.jobs.get("chief", []) or self.jobs.get("master", [])
+
+    @property
+    def trainer_hosts(self) -> List[str]:
+        """Every task that trains: the chief replica first, then the workers."""
+        return self.chief_hosts + self.worker_hosts
+
+    @property
     def num_workers(self) -> int:
-        return max(1, len(self.worker_hosts))
+        return max(1, len(self.trainer_hosts))
+
+    @property
+    def trainer_index(self) -> int:
+        """Rank of this task among the training tasks (chief replica = 0, worker i = i + #chiefs)."""
+        if self.task_type == "worker":
+            return self.task_index + len(self.chief_hosts)
+        return self.task_index
+
+    @property
+    def is_trainer(self) -> bool:
+        return self.task_type in (None, "worker", "chief", "master")
 
     @property
     def is_chief(self) -> bool:
-        """Worker 0 is the chief.  (The reference computes ``index == 0`` for
+        """The first training task is the chief.  (The reference computes ``index == 0`` for
         every job type, so ps 0 also believes it is chief,
-        recognition_flower/distributed/train_dataset.py:138; only workers are
+        recognition_flower/distributed/train_dataset.py:138; only training tasks are
         chiefs here.)"""
-        return self.task_type in (None, "worker", "chief") and self.task_index == 0
+        return self.is_trainer and self.trainer_index == 0
 
     def address(self, job: str, index: int) -> Tuple[str, int]:
         host, _, port = self.jobs[job][index].rpartition(":")
@@ -82,9 +104,9 @@ def torchrun_env() -> Optional[Tuple[int, int, int]]:
 def rendezvous_from_cluster(spec: ClusterSpec) -> Dict[str, str]:
     """Environment for ``torch.distributed.init_process_group(init_method='env://')``
     built from the worker list of a TF_CONFIG cluster."""
-    if not spec.worker_hosts:
+    if not spec.trainer_hosts:
         raise ValueError("cluster has no workers")
-    host, port = spec.address("worker", 0)
+    host, _, port = spec.trainer_hosts[0].rpartition(":")
     return {"MASTER_ADDR": "127.0.0.1" if host in ("localhost", "") else host,
-            "MASTER_PORT": str(port + 1000),
-            "RANK": str(spec.task_index), "WORLD_SIZE": str(len(spec.worker_hosts))}
+            "MASTER_PORT": str(int(port) + 1000),
+            "RANK": str(spec.trainer_index), "WORLD_SIZE": str(len(spec.trainer_hosts))}

@@ -134,7 +134,7 @@ def run_worker(spec):
     from distributed_tensorflow_amd.utils.cluster import rendezvous_from_cluster, torchrun_env
 
     device = _device()
-    task_index = spec.task_index
+    task_index = spec.trainer_index
     world = spec.num_workers
     tr = torchrun_env()
     if spec.task_type is None and tr is not None:
@@ -231,6 +231,10 @@ def main(unused_argv):
     spec = parse_tf_config()
     if spec.task_type == "ps":
         return run_ps(spec)
+    if not spec.is_trainer:
+        # e.g. an "evaluator" replica of a TFJob: the reference has no evaluation loop to run there
+        print("task type %r has no role in this trainer; exiting" % spec.task_type)
+        return 0
     return run_worker(spec)
 
 

@@ -103,3 +103,23 @@ def test_tf_config_from_env(monkeypatch):
     assert cluster.parse_tf_config().task_type == "ps"
     monkeypatch.delenv("TF_CONFIG")
     assert cluster.parse_tf_config().task_type is None
+
+
+def test_tfjob_style_cluster_with_chief_replica():
+    """Kubeflow TFJob writes a separate chief replica: it is trainer 0, the workers follow."""
+    from distributed_tensorflow_amd.utils.cluster import parse_tf_config, rendezvous_from_cluster
+
+    cluster = {"chief": ["c0:2222"], "worker": ["w0:2222", "w1:2222"], "ps": ["p0:2222"]}
+    chief = parse_tf_config(json.dumps({"cluster": cluster, "task": {"type": "chief", "index": 0}}))
+    w1 = parse_tf_config(json.dumps({"cluster": cluster, "task": {"type": "worker", "index": 1}}))
+    ps = parse_tf_config(json.dumps({"cluster": cluster, "task": {"type": "ps", "index": 0}}))
+    assert chief.is_chief and chief.trainer_index == 0 and chief.num_workers == 3
+    assert not w1.is_chief and w1.trainer_index == 2 and w1.num_workers == 3
+    assert not ps.is_chief and not ps.is_trainer
+    env = rendezvous_from_cluster(w1)
+    assert env == {"MASTER_ADDR": "c0", "MASTER_PORT": "3222", "RANK": "2", "WORLD_SIZE": "3"}
+    # the reference's own form: no chief job, worker 0 is the chief
+    plain = parse_tf_config(json.dumps({"cluster": {"worker": ["a:1", "b:2"], "ps": ["p:3"]},
+                                        "task": {"type": "worker", "index": 0}}))
+    assert plain.is_chief and plain.trainer_index == 0 and plain.num_workers == 2
+    assert rendezvous_from_cluster(plain)["MASTER_PORT"] == "1001"
