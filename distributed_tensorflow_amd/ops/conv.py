@@ -191,10 +191,12 @@ def pick_fwd_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
     return bm, bn, bk, (2 if bk == 64 else 3)
 
 
-def pick_wgrad_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
+def pick_wgrad_tile(M: int, cout: int, K: int, cin: int = 0) -> Tuple[int, int, int, int]:
     forced = _env_tile("DTFA_WGRAD_TILE")
     bmw = 128 if cout > 64 else 64
     bnw = 128 if (K > 64 and cout > 64) else 64  # narrow outputs: 64x64 tiles won every such shape in the sweep
+    if 0 < cin <= 16 and K >= 256:
+        bnw = 128  # image-like inputs (the 7x7 stem): many taps of a few channels each, -15 % with the wide K tile
     # a small output over very many pixels with a 128-wide X tile (the 56x56 256->64 / 256->128 1x1 layers at
     # large batch) is bound by streaming dY and X: a 64-pixel k-step halves the barriers per byte moved
     # (+4 .. 10 % there); everywhere else 32 pixels with three stages measured faster
@@ -372,7 +374,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
     M = B * plan.oh * plan.ow
     if M >= 1 << 31 or B * plan.ih * plan.iw >= 1 << 31:
         raise ValueError("too many pixels for 32-bit indices")
-    bmw, bnw, bkp, splits = pick_wgrad_tile(M, plan.cout, plan.K)
+    bmw, bnw, bkp, splits = pick_wgrad_tile(M, plan.cout, plan.K, plan.cin)
     n = plan.cout * plan.K
     slab = hipk.workspace(x.device, splits * n * 4)
     if out is None:
