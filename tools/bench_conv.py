@@ -68,6 +68,16 @@ INCEPTION = [
 ]
 
 
+# Flower CNN at 224x224 (models/flower_cnn.py): TF "SAME" padding (stride 2 on an even size pads the end only)
+FLOWER = [
+    (224, 224, 8, 32, (3, 3), 2, (0, 1, 0, 1)),
+    (112, 112, 32, 64, (3, 3), 1, (1, 1, 1, 1)),
+    (56, 56, 64, 128, (3, 3), 1, (1, 1, 1, 1)),
+    (28, 28, 128, 256, (3, 3), 1, (1, 1, 1, 1)),
+    (14, 14, 256, 512, (3, 3), 1, (1, 1, 1, 1)),
+]
+
+
 def normalise(shape):
     """(H, W, Cin, Cout, (kh, kw), stride, pads4, weight) from either table's row format."""
     H, W, Cin, Cout, k, s, pad = shape[:7]
@@ -92,13 +102,13 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--reference", action="store_true")
     ap.add_argument("--only", type=int, default=-1)
-    ap.add_argument("--shapes", default="resnet", choices=["resnet", "inception"])
+    ap.add_argument("--shapes", default="resnet", choices=["resnet", "inception", "flower"])
     ap.add_argument("--fwd_only", action="store_true")
     args = ap.parse_args()
     B = args.batch
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0, "ref_fwd": 0.0, "ref_bwd": 0.0}
     print("%-28s %8s | %8s %7s | %8s %7s | %8s %7s" % ("shape", "GFLOP", "fwd us", "TF/s", "dgrad us", "TF/s", "wgrad us", "TF/s"))
-    table = RESNET if args.shapes == "resnet" else INCEPTION
+    table = {"resnet": RESNET, "inception": INCEPTION, "flower": FLOWER}[args.shapes]
     for i, shape in enumerate(table):
         if args.only >= 0 and i != args.only:
             continue
