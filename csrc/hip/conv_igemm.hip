@@ -413,7 +413,10 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 :
       for (int i = 0; i < NA; ++i) {
         int iy = aiy[i] + dy, ix = aix[i] + dx;
         bool ok = kvalid && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-        const bf16* src = ok ? abase[i] + ((size_t)(iy * p.IW + ix) * p.Cin + ci) : p.zero;
+        // element offset inside the image with two full-rate 24-bit multiplies (the launcher checks
+        // IH * IW < 2^24 and IH * IW * Cin < 2^32); the 64-bit form costs two quarter-rate multiplies per row
+        const unsigned off = __umul24(__umul24((unsigned)iy, (unsigned)p.IW) + (unsigned)ix, (unsigned)p.Cin) + (unsigned)ci;
+        const bf16* src = ok ? abase[i] + off : p.zero;
         glds16(src, sa + (i * 4 + wid) * 1024);
       }
     }
@@ -651,6 +654,7 @@ extern "C" int dtfa_conv_stats_rows(int M, int bm) {
 extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int nst, hipStream_t stream) {
   if (a->Cin % 8 != 0 || a->Cout % 8 != 0 || a->T > MAX_TAPS || a->T < 1) return -1;
   if (a->K != a->T * a->Cin || a->K >= (1 << 16)) return -2;
+  if ((long long)a->IH * a->IW >= (1ll << 24) || (long long)a->IH * a->IW * a->Cin >= (1ll << 32)) return -2;
   if (a->stats != nullptr && a->bias != nullptr) return -4;
   if (a->addend != nullptr && (a->bias != nullptr || a->relu || (a->stats != nullptr && a->bn_y == nullptr))) return -4;
   if (a->bn_y != nullptr) {
