@@ -311,7 +311,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
 // ~12 TB/s chip-wide with ~90 % L2 hits) is what bounds the compute-heavy layers, and sharing the weight tile
 // takes a quarter of the bytes per FLOP away at 128 x 128.
 template <int BM, int BN, int BK, int EPI, int NST, int WG>
-__global__ __launch_bounds__(256 * WG, (WG == 2 ? 2 : (BM * BN > 128 * 128 ? 2 : (BM * BN <= 128 * 64 ? CONV_NARROW_OCC : 3)))) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN > 128 * 128 ? 2 : (BM * BN <= 128 * 64 ? CONV_NARROW_OCC : 3)))) void conv_igemm_kernel(ConvArgs p) {
   constexpr int S = BK / 8;            // 16-byte slots per LDS row
   constexpr int ROWB = BK * 2;         // bytes per LDS row
   constexpr int RPI = 1024 / ROWB;     // rows covered by one wave-instruction
@@ -668,6 +668,8 @@ extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int ns
   if (bm == 256 && bn == 128 && bk == 32 && nst == 3) return launch_conv_epi<128, 128, 32, 3, 2>(*a, stream);
   if (bm == 256 && bn == 128 && bk == 32 && nst == 2) return launch_conv_epi<128, 128, 32, 2, 2>(*a, stream);
   if (bm == 256 && bn == 128 && bk == 64 && nst == 2) return launch_conv_epi<128, 128, 64, 2, 2>(*a, stream);
+  if (bm == 256 && bn == 256 && bk == 32 && nst == 3) return launch_conv_epi<128, 256, 32, 3, 2>(*a, stream);
+  if (bm == 256 && bn == 256 && bk == 64 && nst == 2) return launch_conv_epi<128, 256, 64, 2, 2>(*a, stream);
 #define CASE(BM_, BN_, BK_)                                                                   \
   if (bm == BM_ && bn == BN_ && bk == BK_) {                                                  \
     if (nst == 2) return launch_conv_epi<BM_, BN_, BK_, 2>(*a, stream);                       \

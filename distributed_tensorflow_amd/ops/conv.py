@@ -154,6 +154,9 @@ def get_plan(ih, iw, cin, cout, kh, kw, sy, sx, pads, device) -> ConvPlan:
 _FWD_TILES = {(128, 192), (128, 128), (128, 64), (64, 64)}
 
 
+# 256 x 256 macro tile for wide, deep layers.
+_BIG = os.environ.get("DTFA_CONV_BIG", "1") == "1"
+_BIG_MIN_BLOCKS = int(os.environ.get("DTFA_CONV_BIG_MIN_BLOCKS", "300"))
 # 256 x 128 macro tile (512-thread workgroups) for compute-bound layers.
 _WIDE = os.environ.get("DTFA_CONV_WIDE", "1") == "1"
 _WIDE_MIN_K = int(os.environ.get("DTFA_CONV_WIDE_MIN_K", "256"))
@@ -168,13 +171,19 @@ def _env_tile(name: str):
     return tuple(int(t) for t in v.split(","))
 
 
-def pick_fwd_tile(M: int, cout: int, K: int) -> Tuple[int, int, int, int]:
+def pick_fwd_tile(M: int, cout: int, K: int, dense: bool = True) -> Tuple[int, int, int, int]:
     """(BM, BN, BK, LDS stages) of the implicit-GEMM kernel.  Chosen from a sweep over the ResNet-50 layer shapes
     and Inception-v3 layer shapes on MI355X (tools/sweep_conv.py, profiles/tile_sweep_b256.md); a 256-row
     tile never won."""
     forced = _env_tile("DTFA_CONV_TILE")
     if forced:
         return tuple(forced) if len(forced) == 4 else tuple(forced) + (2,)  # type: ignore[return-value]
+    # 256 x 256 macro tile (512 threads, each wave 64 x 128, two 64 KB stages, one workgroup per CU): half the
+    # L2 -> LDS bytes per FLOP of the 256 x 128 tile, which is what bounds the wide deep layers (14x14 / 7x7
+    # stages: +5 .. 25 % at batch 1024).  Needs at least a workgroup per CU and a dense (unit output stride)
+    # launch; the strided data-gradient phases have too few taps each.
+    if _BIG and dense and cout % 256 == 0 and K >= 512 and -(-M // 256) * (cout // 256) >= _BIG_MIN_BLOCKS:
+        return 256, 256, 64, 2
     # k-depth: deep reductions amortise the per-tile barrier with BK = 64 (two 32 KB stages, two workgroups per
     # CU); below K = 1024 three 16 KB stages (two k-tiles of loads in flight, three workgroups per CU) win.
     bk = 64 if K >= 1024 else 32
@@ -219,8 +228,8 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
                   bn_tap=None):
     M = B * oyn * oxn
     K = T * cin
-    bm, bn, bk, nst = pick_fwd_tile(M, cout, K)
     dense_out = osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow
+    bm, bn, bk, nst = pick_fwd_tile(M, cout, K, dense_out)
     L = hipk.lib()
     part = None
     if stats or bn_tap is not None:
