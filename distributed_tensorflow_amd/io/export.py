@@ -10,14 +10,19 @@ recognition_flower/distributed/save_model.py:116-171):
 ``predict_images``   method ``tensorflow/serving/predict``; input ``images`` =
     JPEG byte strings; outputs ``classes`` and ``scores``.
 
-``saved_model.pb`` is a serialized TensorFlow graph and cannot be produced
-without TensorFlow, so the export here is a *servable bundle* with the same
-directory contract and the same request / response contract::
+The export keeps the directory contract and the request / response contract::
 
-    <output_dir>/<model_version>/saved_model.json            signature manifest, class vocabulary,
-                                                             preprocessing spec, model recipe
+    <output_dir>/<model_version>/saved_model.pb              SavedModel message: one MetaGraphDef tagged
+                                                             "serve" with the SaverDef, the variable
+                                                             collections, legacy_init_op and both
+                                                             SignatureDefs (io/metagraph.py)
+    <output_dir>/<model_version>/saved_model.json            class vocabulary, preprocessing spec, model recipe
     <output_dir>/<model_version>/variables/variables.index   Saver-V2 bundle (TensorFlow variable names)
     <output_dir>/<model_version>/variables/variables.data-00000-of-00001
+
+``graph_def`` inside ``saved_model.pb`` is empty: a TensorFlow graph is a program for TensorFlow's
+executor, which does not exist here.  The network is rebuilt from the model recipe in the manifest and the
+variables; the signatures are read back from ``saved_model.pb``.
 
 :class:`Servable` loads such a directory and answers both signatures.  Scores
 are the raw top-1 logits, exactly like the reference (``tf.nn.top_k(logits, 1)``,
@@ -41,21 +46,54 @@ from .saver import Saver
 from .tfrecord import make_example, parse_example
 
 MANIFEST = "saved_model.json"
+SAVED_MODEL_PB = "saved_model.pb"
 
 
 def signature_manifest() -> Dict:
+    """The two signatures with the tensors the reference binds them to: the ``tf_example`` placeholder (declared
+    without a shape), the parsed ``image/encoded`` column, and ``top_k(logits, 1)`` values / looked-up class strings
+    created under ``name_scope('train')`` (recognition_flower/single/flower_train.py:120-127,154-156,207-237).
+    Tensor names are nominal: no graph exists for them to resolve in."""
+    classes = {"dtype": "string", "tensor": "train/index_to_string_Lookup:0", "shape": [-1, 1]}
+    scores = {"dtype": "float", "tensor": "train/TopKV2:0", "shape": [-1, 1]}
     return {
         "serving_default": {
             "method_name": "tensorflow/serving/classify",
-            "inputs": {"inputs": {"dtype": "string", "description": "serialized tf.Example with image/encoded"}},
-            "outputs": {"classes": {"dtype": "string"}, "scores": {"dtype": "float"}},
+            "inputs": {"inputs": {"dtype": "string", "tensor": "tf_example:0", "shape": None,
+                                  "description": "serialized tf.Example with image/encoded"}},
+            "outputs": {"classes": dict(classes), "scores": dict(scores)},
         },
         "predict_images": {
             "method_name": "tensorflow/serving/predict",
-            "inputs": {"images": {"dtype": "string", "description": "JPEG bytes"}},
-            "outputs": {"classes": {"dtype": "string"}, "scores": {"dtype": "float"}},
+            "inputs": {"images": {"dtype": "string", "tensor": "ParseExample/ParseExample:0", "shape": [-1],
+                                  "description": "JPEG bytes"}},
+            "outputs": {"classes": dict(classes), "scores": dict(scores)},
         },
     }
+
+
+def read_signatures(export_path: str) -> Dict:
+    """SignatureDefs of an export, from its ``saved_model.pb``."""
+    from .metagraph import decode_saved_model
+
+    with open(os.path.join(export_path, SAVED_MODEL_PB), "rb") as f:
+        sm = decode_saved_model(f.read())
+    if "serve" not in sm["tags"]:
+        raise ValueError("%s holds no meta graph tagged 'serve'" % export_path)
+    return sm["signature_def"]
+
+
+def signature_def_json(sigs: Dict) -> Dict:
+    """SignatureDefs in the JSON form of a model server's metadata reply (TensorInfo as ``name`` / ``dtype`` =
+    ``DT_*`` / ``tensor_shape`` with string dimension sizes, the proto3 JSON mapping of int64)."""
+    def info(d):
+        shape = d.get("shape")
+        return {"name": d["tensor"], "dtype": "DT_" + d["dtype"].upper(),
+                "tensor_shape": {"dim": [{"size": str(x), "name": ""} for x in (shape or [])],
+                                 "unknown_rank": shape is None}}
+    return {k: {"inputs": {n: info(d) for n, d in s["inputs"].items()},
+                "outputs": {n: info(d) for n, d in s["outputs"].items()},
+                "method_name": s["method_name"]} for k, s in sigs.items()}
 
 
 def export_servable(model, classes: Sequence[str], output_dir: str, model_version: int, *, model_name: str,
@@ -71,6 +109,12 @@ def export_servable(model, classes: Sequence[str], output_dir: str, model_versio
     saver = Saver(model, engine)
     tensors = saver.variables(include_slots=False)
     bundle.write_bundle(os.path.join(export_path, "variables", "variables"), tensors)
+    from .metagraph import encode_saved_model
+
+    trainable = {v.name: v.trainable for v in saver.specs}
+    names = [(n, trainable.get(n, False)) for n in sorted(tensors, key=lambda k: k.encode())]
+    with open(os.path.join(export_path, SAVED_MODEL_PB), "wb") as f:
+        f.write(encode_saved_model(names, signature_manifest()))
     manifest = {
         "format": "dtfa-servable-1",
         "tags": ["serve"],
@@ -101,6 +145,9 @@ class Servable:
         if self.manifest.get("format") != "dtfa-servable-1":
             raise ValueError("unknown servable format")
         self.classes: List[str] = self.manifest["classes"]
+        pb = os.path.join(export_path, SAVED_MODEL_PB)
+        #: SignatureDefs as exported (saved_model.pb); exports older than that file carry them in the manifest only
+        self.signature_def: Dict = read_signatures(export_path) if os.path.exists(pb) else self.manifest["signature_def"]
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
         m = self.manifest["model"]
         self.model = build_model(m["name"], num_classes=m["num_classes"], device=self.device, **m["kwargs"])

@@ -12,6 +12,9 @@ these RPCs:
 ``/tensorflow.serving.PredictionService/Classify``
     ``input.example_list`` (or ``example_list_with_context``) -> one ``Classifications`` per example with the
     top-1 ``Class{label, score}``.
+``/tensorflow.serving.PredictionService/GetModelMetadata``
+    ``metadata_field = ["signature_def"]`` -> ``metadata["signature_def"]`` = ``Any`` wrapping the
+    ``SignatureDefMap`` read from the export's ``saved_model.pb``.
 ``/tensorflow.serving.ModelService/GetModelStatus``
     the versions the manager knows and their state.
 
@@ -39,7 +42,7 @@ class GrpcModelServer:
                  max_workers: int = 16, max_message_mb: int = 64):
         self.manager = manager
         self.batcher = batcher
-        self.calls = {"Predict": 0, "Classify": 0, "GetModelStatus": 0}
+        self.calls = {"Predict": 0, "Classify": 0, "GetModelMetadata": 0, "GetModelStatus": 0}
         opts = [("grpc.max_receive_message_length", max_message_mb << 20),
                 ("grpc.max_send_message_length", max_message_mb << 20)]
         self._server = grpc.server(futures.ThreadPoolExecutor(max_workers=max_workers), options=opts)
@@ -51,6 +54,9 @@ class GrpcModelServer:
                 "Classify": grpc.unary_unary_rpc_method_handler(
                     self._classify, request_deserializer=P.ClassificationRequest.FromString,
                     response_serializer=P.ClassificationResponse.SerializeToString),
+                "GetModelMetadata": grpc.unary_unary_rpc_method_handler(
+                    self._metadata, request_deserializer=P.GetModelMetadataRequest.FromString,
+                    response_serializer=P.GetModelMetadataResponse.SerializeToString),
             }),
             grpc.method_handlers_generic_handler(MODEL_SERVICE, {
                 "GetModelStatus": grpc.unary_unary_rpc_method_handler(
@@ -159,6 +165,22 @@ class GrpcModelServer:
         for c, s in zip(out["classes"], out["scores"]):
             one = resp.result.classifications.add().classes.add()
             one.label, one.score = str(c[0]), float(s[0])
+        return resp
+
+    def _metadata(self, req, context):
+        self.calls["GetModelMetadata"] += 1
+        version = self._check_spec(req.model_spec, context)
+        fields = list(req.metadata_field)
+        if not fields:
+            context.abort(grpc.StatusCode.INVALID_ARGUMENT, "GetModelMetadataRequest must specify at least one metadata_field")
+        if set(fields) != {"signature_def"}:
+            context.abort(grpc.StatusCode.INVALID_ARGUMENT, "metadata field %r is not supported" % sorted(set(fields) - {"signature_def"})[0])
+        servable = self.manager.get(version)
+        resp = P.GetModelMetadataResponse()
+        self._reply_spec(resp, "")
+        if version is not None:
+            resp.model_spec.version.value = int(version)
+        resp.metadata["signature_def"].Pack(P.signature_def_map(servable.signature_def))
         return resp
 
     def _status(self, req, context):

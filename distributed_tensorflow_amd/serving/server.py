@@ -36,6 +36,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
+from ..io.export import signature_def_json
 from ..io.tfrecord import parse_example
 from .batcher import DynamicBatcher, QueueFull
 from .manager import ModelManager
@@ -143,7 +144,7 @@ class ModelServer:
                 self._count("metadata", 404, t0)
                 return 404, {"error": str(e)}, "application/json"
             body = {"model_spec": {"name": self.manager.name, "signature_name": "", "version": str(self.manager.version)},
-                    "metadata": {"signature_def": {"signature_def": servable.manifest["signature_def"]},
+                    "metadata": {"signature_def": {"signature_def": signature_def_json(servable.signature_def)},
                                  "classes": servable.classes, "preprocess": servable.manifest["preprocess"]}}
             self._count("metadata", 200, t0)
             return 200, body, "application/json"

@@ -6,8 +6,8 @@ predict signature, recognition_flower/distributed/save_model.py:126-171) talk
 generated ``*_pb2`` modules exist in this environment, so the message types are
 declared here as descriptors -- message names, field names, field numbers and
 types as in the public ``.proto`` files of TensorFlow (tensor, tensor_shape,
-types, example, feature) and TensorFlow Serving (model, predict, input,
-classification, get_model_status) -- and turned into classes by the protobuf
+types, example, feature, meta_graph) and TensorFlow Serving (model, predict, input,
+classification, get_model_status, get_model_metadata) -- and turned into classes by the protobuf
 runtime.  Only the fields a served image classifier uses are declared; unknown
 fields sent by a client are preserved and ignored, as protobuf prescribes.
 
@@ -17,7 +17,7 @@ declarations produce.
 """
 from __future__ import annotations
 
-from google.protobuf import descriptor_pb2, descriptor_pool, message_factory, wrappers_pb2  # noqa: F401
+from google.protobuf import any_pb2, descriptor_pb2, descriptor_pool, message_factory, wrappers_pb2  # noqa: F401
 
 _F = descriptor_pb2.FieldDescriptorProto
 _T = {"int32": _F.TYPE_INT32, "int64": _F.TYPE_INT64, "float": _F.TYPE_FLOAT, "double": _F.TYPE_DOUBLE,
@@ -99,6 +99,17 @@ def _build():
     ex = fd.message_type.add()
     ex.name = "Example"
     _field(ex, "features", 1, ".tensorflow.Features")
+    tinfo = fd.message_type.add()
+    tinfo.name = "TensorInfo"
+    tinfo.oneof_decl.add().name = "encoding"
+    _field(tinfo, "name", 1, "string", oneof=0)
+    _field(tinfo, "dtype", 2, "enum:.tensorflow.DataType")
+    _field(tinfo, "tensor_shape", 3, ".tensorflow.TensorShapeProto")
+    sigdef = fd.message_type.add()
+    sigdef.name = "SignatureDef"
+    _map_field(sigdef, "inputs", 1, ".tensorflow.TensorInfo", ".tensorflow.SignatureDef")
+    _map_field(sigdef, "outputs", 2, ".tensorflow.TensorInfo", ".tensorflow.SignatureDef")
+    _field(sigdef, "method_name", 3, "string")
     pool.Add(fd)
 
     # ---------------------------------------------------------------- tensorflow serving
@@ -106,6 +117,7 @@ def _build():
     sd.name, sd.package, sd.syntax = "dtfa/tensorflow_serving.proto", "tensorflow.serving", "proto3"
     sd.dependency.append("dtfa/tensorflow_core.proto")
     sd.dependency.append("google/protobuf/wrappers.proto")
+    sd.dependency.append("google/protobuf/any.proto")
     spec = sd.message_type.add()
     spec.name = "ModelSpec"
     spec.oneof_decl.add().name = "version_choice"
@@ -173,23 +185,38 @@ def _build():
     gsp = sd.message_type.add()
     gsp.name = "GetModelStatusResponse"
     _field(gsp, "model_version_status", 1, ".tensorflow.serving.ModelVersionStatus", repeated=True)
+    # model metadata
+    sdm = sd.message_type.add()
+    sdm.name = "SignatureDefMap"
+    _map_field(sdm, "signature_def", 1, ".tensorflow.SignatureDef", ".tensorflow.serving.SignatureDefMap")
+    gmr = sd.message_type.add()
+    gmr.name = "GetModelMetadataRequest"
+    _field(gmr, "model_spec", 1, ".tensorflow.serving.ModelSpec")
+    _field(gmr, "metadata_field", 2, "string", repeated=True)
+    gmp = sd.message_type.add()
+    gmp.name = "GetModelMetadataResponse"
+    _field(gmp, "model_spec", 1, ".tensorflow.serving.ModelSpec")
+    _map_field(gmp, "metadata", 2, ".google.protobuf.Any", ".tensorflow.serving.GetModelMetadataResponse")
     pool.Add(sd)
 
     def cls_of(full_name):
         return message_factory.GetMessageClass(pool.FindMessageTypeByName(full_name))
 
     names = {"TensorProto": "tensorflow.TensorProto", "TensorShapeProto": "tensorflow.TensorShapeProto",
-             "Example": "tensorflow.Example", "Features": "tensorflow.Features", "Feature": "tensorflow.Feature"}
+             "Example": "tensorflow.Example", "Features": "tensorflow.Features", "Feature": "tensorflow.Feature",
+             "TensorInfo": "tensorflow.TensorInfo", "SignatureDef": "tensorflow.SignatureDef"}
     for n in ("ModelSpec", "PredictRequest", "PredictResponse", "Input", "ExampleList", "ClassificationRequest",
               "ClassificationResponse", "ClassificationResult", "Classifications", "Class", "GetModelStatusRequest",
-              "GetModelStatusResponse", "ModelVersionStatus", "StatusProto"):
+              "GetModelStatusResponse", "ModelVersionStatus", "StatusProto", "SignatureDefMap", "GetModelMetadataRequest",
+              "GetModelMetadataResponse"):
         names[n] = "tensorflow.serving." + n
     return {k: cls_of(v) for k, v in names.items()}
 
 
 _classes = _build()
 globals().update(_classes)
-__all__ = sorted(_classes) + ["DT_FLOAT", "DT_STRING", "DT_INT64", "string_tensor", "float_tensor", "tensor_strings"]
+__all__ = sorted(_classes) + ["DT_FLOAT", "DT_STRING", "DT_INT64", "string_tensor", "float_tensor", "tensor_strings",
+                               "signature_def_map"]
 
 DT_FLOAT, DT_STRING, DT_INT64 = 1, 7, 9
 
@@ -218,3 +245,23 @@ def tensor_strings(t):
     if t.dtype != DT_STRING:
         raise ValueError("expected a DT_STRING tensor, got dtype %d" % t.dtype)
     return [bytes(v) for v in t.string_val]
+
+
+def signature_def_map(sigs):
+    """``SignatureDefMap`` from exported signatures ({key: {"method_name", "inputs" / "outputs": {name: {"tensor",
+    "dtype": "string" | "float", "shape": [..] | None}}}}, the layout of ``Servable.signature_def``)."""
+    out = _classes["SignatureDefMap"]()
+    for key, sig in sigs.items():
+        sd = out.signature_def[key]
+        sd.method_name = sig["method_name"]
+        for side, dst in (("inputs", sd.inputs), ("outputs", sd.outputs)):
+            for name, d in sig[side].items():
+                ti = dst[name]
+                ti.name = d["tensor"]
+                ti.dtype = {"string": DT_STRING, "float": DT_FLOAT}[d["dtype"]]
+                if d.get("shape") is None:
+                    ti.tensor_shape.unknown_rank = True
+                else:
+                    for x in d["shape"]:
+                        ti.tensor_shape.dim.add().size = int(x)
+    return out

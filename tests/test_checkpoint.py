@@ -156,3 +156,83 @@ def test_meta_file_lists_the_saved_variables(tmp_path):
     assert "fc_trainable/flower_logits/kernel:0" in trainable and "FlowerCNN/conv1/BatchNorm/moving_mean:0" not in trainable
     assert "fc_trainable/flower_logits/kernel/Adam:0" in names and "fc_trainable/flower_logits/kernel/Adam:0" not in trainable
     assert meta["collections"]["global_step"] == [("global_step:0", False)]
+
+
+def test_saved_model_pb_carries_tags_saver_collections_and_signatures(tmp_path):
+    """``saved_model.pb`` of an export: schema version 1, one meta graph tagged ``serve``, the two signatures of
+    the reference (recognition_flower/single/flower_train.py:207-249) with their TensorInfo, ``legacy_init_op``.
+    The hand-written wire encoding is cross-checked by parsing the same bytes with protobuf-runtime message
+    classes declared from the public saved_model / meta_graph schemas (field numbers written out below)."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+
+    from distributed_tensorflow_amd.io.export import export_servable, read_signatures, signature_manifest
+    from distributed_tensorflow_amd.io.metagraph import decode_saved_model
+
+    model = build_model("flower_cnn", num_classes=3, device=torch.device("cpu"))
+    path = export_servable(model, ["a", "b", "c"], str(tmp_path), 4, model_name="flower_cnn", image_size=32)
+    raw = open(os.path.join(path, "saved_model.pb"), "rb").read()
+    sm = decode_saved_model(raw)
+    assert sm["schema_version"] == 1 and sm["tags"] == ["serve"] and sm["saver"]["version"] == 2
+    assert sm["node_lists"] == {"legacy_init_op": ["legacy_init_op"]}
+    keys = {k for k, *_ in bundle.list_bundle(os.path.join(path, "variables", "variables"))}
+    assert {n[:-2] for n, _ in sm["collections"]["variables"]} == keys
+    want = signature_manifest()
+    got = read_signatures(path)
+    assert set(got) == {"serving_default", "predict_images"}
+    for key in want:
+        assert got[key]["method_name"] == want[key]["method_name"]
+        for side in ("inputs", "outputs"):
+            assert {n: (d["tensor"], d["dtype"], d["shape"]) for n, d in got[key][side].items()} == \
+                   {n: (d["tensor"], d["dtype"], d["shape"]) for n, d in want[key][side].items()}
+
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto()
+    fd.name, fd.package, fd.syntax = "dtfa_test/saved_model.proto", "dtfa_test", "proto3"
+
+    def msg(name, fields, maps=()):
+        m = fd.message_type.add()
+        m.name = name
+        for fname, num, typ, rep in fields:
+            f = m.field.add()
+            f.name, f.number, f.label = fname, num, F.LABEL_REPEATED if rep else F.LABEL_OPTIONAL
+            if typ.startswith("."):
+                f.type, f.type_name = F.TYPE_MESSAGE, typ
+            else:
+                f.type = getattr(F, "TYPE_" + typ.upper())
+        for fname, num, vtyp in maps:
+            e = m.nested_type.add()
+            e.name = "".join(p.capitalize() for p in fname.split("_")) + "Entry"
+            e.options.map_entry = True
+            k = e.field.add()
+            k.name, k.number, k.label, k.type = "key", 1, F.LABEL_OPTIONAL, F.TYPE_STRING
+            v = e.field.add()
+            v.name, v.number, v.label, v.type, v.type_name = "value", 2, F.LABEL_OPTIONAL, F.TYPE_MESSAGE, vtyp
+            f = m.field.add()
+            f.name, f.number, f.label, f.type = fname, num, F.LABEL_REPEATED, F.TYPE_MESSAGE
+            f.type_name = ".dtfa_test.%s.%s" % (name, e.name)
+
+    msg("Dim", [("size", 1, "int64", False)])
+    msg("Shape", [("dim", 2, ".dtfa_test.Dim", True), ("unknown_rank", 3, "bool", False)])
+    msg("TensorInfo", [("name", 1, "string", False), ("dtype", 2, "int32", False), ("tensor_shape", 3, ".dtfa_test.Shape", False)])
+    msg("SignatureDef", [("method_name", 3, "string", False)],
+        maps=[("inputs", 1, ".dtfa_test.TensorInfo"), ("outputs", 2, ".dtfa_test.TensorInfo")])
+    msg("MetaInfoDef", [("tags", 4, "string", True)])
+    msg("SaverDef", [("filename_tensor_name", 1, "string", False), ("sharded", 5, "bool", False), ("version", 7, "int32", False)])
+    msg("MetaGraphDef", [("meta_info_def", 1, ".dtfa_test.MetaInfoDef", False), ("saver_def", 3, ".dtfa_test.SaverDef", False)],
+        maps=[("signature_def", 5, ".dtfa_test.SignatureDef")])
+    msg("SavedModel", [("saved_model_schema_version", 1, "int64", False), ("meta_graphs", 2, ".dtfa_test.MetaGraphDef", True)])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    SavedModel = message_factory.GetMessageClass(pool.FindMessageTypeByName("dtfa_test.SavedModel"))
+    pm = SavedModel.FromString(raw)
+    assert pm.saved_model_schema_version == 1 and len(pm.meta_graphs) == 1
+    mg = pm.meta_graphs[0]
+    assert list(mg.meta_info_def.tags) == ["serve"] and mg.saver_def.version == 2 and mg.saver_def.sharded
+    sd = mg.signature_def["serving_default"]
+    assert sd.method_name == "tensorflow/serving/classify"
+    assert sd.inputs["inputs"].name == "tf_example:0" and sd.inputs["inputs"].dtype == 7
+    assert sd.inputs["inputs"].tensor_shape.unknown_rank and len(sd.inputs["inputs"].tensor_shape.dim) == 0
+    pi = mg.signature_def["predict_images"]
+    assert pi.method_name == "tensorflow/serving/predict" and [d.size for d in pi.inputs["images"].tensor_shape.dim] == [-1]
+    assert pi.outputs["scores"].dtype == 1 and [d.size for d in pi.outputs["scores"].tensor_shape.dim] == [-1, 1]
+    assert pi.outputs["classes"].dtype == 7

@@ -52,13 +52,14 @@ def test_single_trainer_trains_exports_and_serves(tmp_path):
     assert "fc_trainable/dense_prelogit1/kernel" in keys and "fc_trainable/flower_logits/bias/Adam_1" in keys
     # servable: versioned directory, two signatures, class strings + raw-logit scores
     export = out / "models" / "3"
-    assert sorted(os.listdir(export)) == ["saved_model.json", "variables"]
+    assert sorted(os.listdir(export)) == ["saved_model.json", "saved_model.pb", "variables"]
     assert sorted(os.listdir(export / "variables")) == ["variables.data-00000-of-00001", "variables.index"]
     manifest = json.load(open(export / "saved_model.json"))
     assert manifest["signature_def"]["serving_default"]["method_name"] == "tensorflow/serving/classify"
     assert manifest["signature_def"]["predict_images"]["method_name"] == "tensorflow/serving/predict"
     assert manifest["classes"] == ["daisy", "roses", "tulips"]
     s = Servable(str(export), device="cpu")
+    assert s.signature_def["serving_default"]["inputs"]["inputs"]["tensor"] == "tf_example:0"
     jpegs = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(data, "*", "*.jpg")))[:4]]
     a = s.predict_images(jpegs)
     b = s.serving_default([example_from_jpeg(j) for j in jpegs])

@@ -110,6 +110,11 @@ def test_rest_signatures_match_the_servable(served):
     sigs = meta["metadata"]["signature_def"]["signature_def"]
     assert sigs["serving_default"]["method_name"] == "tensorflow/serving/classify"
     assert sigs["predict_images"]["method_name"] == "tensorflow/serving/predict" and meta["metadata"]["classes"] == CLASSES
+    assert sigs["predict_images"]["inputs"]["images"] == {
+        "name": "ParseExample/ParseExample:0", "dtype": "DT_STRING",
+        "tensor_shape": {"dim": [{"size": "-1", "name": ""}], "unknown_rank": False}}
+    assert sigs["serving_default"]["inputs"]["inputs"]["tensor_shape"] == {"dim": [], "unknown_rank": True}
+    assert sigs["serving_default"]["outputs"]["scores"]["dtype"] == "DT_FLOAT"
     # predict, row format (bare values and named values) and columnar format
     code, row = _call(port, "/v1/models/flowers:predict", {"instances": [_b64(j) for j in jpegs]})
     assert code == 200 and len(row["predictions"]) == 6
@@ -208,7 +213,7 @@ def test_serve_model_entrypoint(tmp_path):
 
 
 def test_grpc_prediction_service(served):
-    """Predict / Classify / GetModelStatus over gRPC agree with the servable and with the REST front end."""
+    """Predict / Classify / GetModelMetadata / GetModelStatus over gRPC agree with the servable and with the REST front end."""
     import grpc
 
     from distributed_tensorflow_amd.serving import GrpcModelServer
@@ -264,6 +269,33 @@ def test_grpc_prediction_service(served):
         sreq.model_spec.name = "flowers"
         st = status(sreq, timeout=30)
         assert [(m.version, m.state) for m in st.model_version_status] == [(1, 30)]
+        # metadata: the SignatureDefMap of saved_model.pb, packed in an Any
+        metadata = ch.unary_unary("/tensorflow.serving.PredictionService/GetModelMetadata",
+                                  request_serializer=P.GetModelMetadataRequest.SerializeToString,
+                                  response_deserializer=P.GetModelMetadataResponse.FromString)
+        mreq = P.GetModelMetadataRequest()
+        mreq.model_spec.name = "flowers"
+        mreq.metadata_field.append("signature_def")
+        mresp = metadata(mreq, timeout=30)
+        assert mresp.model_spec.version.value == 1
+        assert mresp.metadata["signature_def"].type_url == "type.googleapis.com/tensorflow.serving.SignatureDefMap"
+        sdm = P.SignatureDefMap()
+        assert mresp.metadata["signature_def"].Unpack(sdm) and set(sdm.signature_def) == {"serving_default", "predict_images"}
+        sd = sdm.signature_def["serving_default"]
+        assert sd.method_name == "tensorflow/serving/classify" and sd.inputs["inputs"].name == "tf_example:0"
+        assert sd.inputs["inputs"].dtype == P.DT_STRING and sd.inputs["inputs"].tensor_shape.unknown_rank
+        assert [d.size for d in sdm.signature_def["predict_images"].outputs["scores"].tensor_shape.dim] == [-1, 1]
+        # the message built by the protobuf runtime and the hand-encoded saved_model.pb agree byte for byte per signature
+        from distributed_tensorflow_amd.io.metagraph import signature_def, tensor_info
+        from distributed_tensorflow_amd.io.export import signature_manifest
+        for key, sig in signature_manifest().items():
+            ti = {side: {n: tensor_info(d["tensor"], d["dtype"], d.get("shape")) for n, d in sig[side].items()}
+                  for side in ("inputs", "outputs")}
+            assert sdm.signature_def[key].SerializeToString(deterministic=True) == \
+                signature_def(ti["inputs"], ti["outputs"], sig["method_name"])
+        with pytest.raises(grpc.RpcError) as e:
+            metadata(P.GetModelMetadataRequest(), timeout=30)
+        assert e.value.code() == grpc.StatusCode.INVALID_ARGUMENT
         # errors carry gRPC status codes
         bad = P.PredictRequest()
         bad.model_spec.name = "other"
