@@ -37,42 +37,13 @@ DEFAULT_BATCH = {"resnet50": 2048, "flower_cnn": 1024, "inception_v3_head": 256}
 IMAGE_SIZE = {"resnet50": 224, "flower_cnn": 224, "inception_v3_head": 299}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="resnet50", choices=sorted(DEFAULT_BATCH))
-    ap.add_argument("--mode", default="sync_dp", choices=["sync_dp", "sharded_ps", "async_ssp"])
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default depends on the model)")
-    ap.add_argument("--bucket_mb", type=float, default=32.0)
-    ap.add_argument("--staleness", type=int, default=1)
-    ap.add_argument("--p2p_kb", type=int, default=0,
-                    help="gradient buckets up to this many KiB use the one-shot xGMI mailbox all-reduce (sync_dp)")
-    ap.add_argument("--hip_graph", type=int, default=0,
-                    help="1: record the whole step (fwd, bwd, collectives, optimizer) in a HIP graph and replay it")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X GPU")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run, any N
-    if world > 1 or launched:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d; reporting WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-
-    batch = args.batch or DEFAULT_BATCH[args.model]
-    size = IMAGE_SIZE[args.model]
+def run_config(args, model_name, batch, device, rank, world):
+    """W untimed + K timed complete training steps of one model; returns the whole-job images/s (max time over ranks)."""
+    size = IMAGE_SIZE[model_name]
     torch.manual_seed(1234)
-    model = build_model(args.model, num_classes=5, device=device)
+    model = build_model(model_name, num_classes=5, device=device)
     model.train()
-    if args.model == "inception_v3_head":
+    if model_name == "inception_v3_head":
         opt, lr, okw = "adam", 1e-3, {}
     else:
         # a fixed synthetic batch with random labels: a small constant rate keeps the loss finite at any world size
@@ -130,25 +101,75 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
     ips = batch * world * args.steps / dt
+    return {"value": round(ips, 2), "ms_per_step": round(dt / args.steps * 1e3, 3), "final_loss": round(float(loss.item()), 4),
+            "per_gpu_batch": batch, "global_batch": batch * world, "optimizer": opt,
+            "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2**30, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="resnet50", choices=sorted(DEFAULT_BATCH))
+    ap.add_argument("--mode", default="sync_dp", choices=["sync_dp", "sharded_ps", "async_ssp"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default depends on the model)")
+    ap.add_argument("--bucket_mb", type=float, default=32.0)
+    ap.add_argument("--staleness", type=int, default=1)
+    ap.add_argument("--p2p_kb", type=int, default=0,
+                    help="gradient buckets up to this many KiB use the one-shot xGMI mailbox all-reduce (sync_dp)")
+    ap.add_argument("--also", default="flower_cnn",
+                    help="second model measured after the headline one and reported under \"also\" ('' = none)")
+    ap.add_argument("--hip_graph", type=int, default=0,
+                    help="1: record the whole step (fwd, bwd, collectives, optimizer) in a HIP graph and replay it")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run, any N
+    if world > 1 or launched:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d; reporting WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    head = run_config(args, args.model, args.batch or DEFAULT_BATCH[args.model], device, rank, world)
+    also = {}
+    if args.also and args.also != args.model:
+        # the second model of the headline metric (flower CNN), same K / W, measured after the headline run
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            r = run_config(args, args.also, DEFAULT_BATCH[args.also], device, rank, world)
+            also = {args.also: {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "final_loss")}}
+        except Exception as e:  # noqa: BLE001 -- the headline number stands on its own
+            also = {args.also: {"error": "%s: %s" % (type(e).__name__, e)}}
     if rank == 0:
         print(json.dumps({
             "metric": "train images/sec (whole node)",
-            "value": round(ips, 2),
+            "value": head["value"],
             "unit": "images/sec",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "final_loss": round(float(loss.item()), 4),
-            "config": {"model": args.model, "global_batch": batch * world, "per_gpu_batch": batch,
-                       "image_size": size, "num_classes": 5, "parallelism": "dp%d" % world, "mode": args.mode,
-                       "optimizer": opt, "hip_graph": bool(args.hip_graph)},
-            "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2**30, 2),
+            "final_loss": head["final_loss"],
+            "config": {"model": args.model, "global_batch": head["global_batch"], "per_gpu_batch": head["per_gpu_batch"],
+                       "image_size": IMAGE_SIZE[args.model], "num_classes": 5, "parallelism": "dp%d" % world,
+                       "mode": args.mode, "optimizer": head["optimizer"], "hip_graph": bool(args.hip_graph)},
+            "peak_mem_gb": head["peak_mem_gb"],
+            "also": also,
         }), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -8,8 +8,17 @@ def main():
     d = sys.argv[1]
     steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
     title = sys.argv[3] if len(sys.argv) > 3 else d
-    f = glob.glob(d + "/**/*_kernel_stats.csv", recursive=True)[0]
-    rows = list(csv.DictReader(open(f)))
+    found = glob.glob(d + "/**/*_kernel_stats.csv", recursive=True)
+    if found:
+        rows = list(csv.DictReader(open(found[0])))
+    else:
+        # rocprofv3's default output is a rocpd SQLite database; build the same per-kernel rows from its dispatch table
+        import sqlite3
+        db = sqlite3.connect(glob.glob(d + "/**/*_results.db", recursive=True)[0])
+        q = db.execute("select name, count(*), sum(end - start), avg(end - start) from kernels group by name order by 3 desc").fetchall()
+        total = float(sum(r[2] for r in q))
+        rows = [{"Name": n, "Calls": str(c), "TotalDurationNs": str(t), "AverageNs": str(a), "Percentage": str(100.0 * t / total)}
+                for n, c, t, a in q]
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     cats = {}
 
