@@ -41,7 +41,8 @@ def run_config(args, model_name, batch, device, rank, world):
     """W untimed + K timed complete training steps of one model; returns the whole-job images/s (max time over ranks)."""
     size = IMAGE_SIZE[model_name]
     torch.manual_seed(1234)
-    model = build_model(model_name, num_classes=5, device=device)
+    kw = {"trunk_bn": args.trunk_bn} if model_name == "inception_v3_head" else {}
+    model = build_model(model_name, num_classes=5, device=device, **kw)
     model.train()
     if model_name == "inception_v3_head":
         opt, lr, okw = "adam", 1e-3, {}
@@ -118,6 +119,8 @@ def main():
     ap.add_argument("--staleness", type=int, default=1)
     ap.add_argument("--p2p_kb", type=int, default=0,
                     help="gradient buckets up to this many KiB use the one-shot xGMI mailbox all-reduce (sync_dp)")
+    ap.add_argument("--trunk_bn", default="batch", choices=["batch", "moving"],
+                    help="inception_v3_head: trunk batch-norm on batch statistics (reference) or frozen moving statistics")
     ap.add_argument("--also", default="flower_cnn",
                     help="second model measured after the headline one and reported under \"also\" ('' = none)")
     ap.add_argument("--hip_graph", type=int, default=0,

@@ -57,6 +57,9 @@ struct ConvArgs {
   const float* bn_shift;         // [Cout]
   const unsigned char* bn_mask;  // one bit per output element (bn_relu == 3)
   int bn_relu;                   // 0: no gating, 2: recompute, 3: stored bits
+  // bias / ReLU epilogue only (inference with folded batch-norm, dense layers):
+  int ldo;                       // channel pitch of the output rows (> Cout: y is a channel slice of a wider tensor)
+  const float* oscale;           // [Cout] multiplier applied to the accumulator before the bias, or null
 };
 
 #define MAX_TAPS 64
@@ -105,6 +108,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
   const int wid = w4;
   const int khalf = lane >> 5;
   const int opix = p.OYn * p.OXn;
+  const int ldo = EPI == 2 ? p.ldo : p.Cout;  // only the bias / ReLU epilogue writes into channel slices
   // ---- epilogue: bias / relu / bn partial statistics / bf16 rows via LDS ----
   // Row readback geometry: a wave-instruction covers RPP rows x CPR 16-byte chunks; lane -> (row, chunk)
   // is the same in every pass, so a lane keeps one chunk column (8 channels).
@@ -131,7 +135,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
         opixel = ((size_t)b * p.OH + (oy * p.osy + p.oy0)) * p.OW + (ox * p.osx + p.ox0);
       }
     }
-    return opixel * p.Cout + chunk_co;
+    return opixel * ldo + chunk_co;
   };
   char* ep = lds_tiles + wid * (WM * EP_PITCH);
   float* xch = (float*)(lds_tiles + 4 * WM * EP_PITCH);  // [2 wave columns][WN][2] exchange area behind the row tiles
@@ -140,8 +144,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int co = n0 + wc * WN + nt * 32 + colq;
-    float bias = 0.f;
+    float bias = 0.f, osc = 1.f;
     if (EPI == 2 && p.bias != nullptr && co < p.Cout) bias = p.bias[co];
+    if (EPI == 2 && p.oscale != nullptr && co < p.Cout) osc = p.oscale[co];
     const bool relu = EPI == 2 && p.relu != 0;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -150,7 +155,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
       for (int j = 0; j < 16; ++j) {
         float v = acc[mt][nt][j];
         if (EPI == 2) {
-          v += bias;
+          v = v * osc + bias;
           if (relu) v = fmaxf(v, 0.f);
         }
         if (EPI == 1) {  // statistics of the fp32 accumulators (rounding to bf16 is unbiased)
@@ -640,7 +645,8 @@ template <int BM, int BN, int BK, int NST, int WG = 1>
 static int launch_conv_epi(const ConvArgs& a, hipStream_t stream) {
   if (a.bn_y != nullptr) return launch_conv<BM, BN, BK, 3, NST, WG>(a, stream);
   if (a.stats != nullptr) return launch_conv<BM, BN, BK, 1, NST, WG>(a, stream);
-  if (a.bias != nullptr || a.relu) return launch_conv<BM, BN, BK, 2, NST, WG>(a, stream);
+  if (a.bias != nullptr || a.relu || a.oscale != nullptr || a.ldo != a.Cout)
+    return launch_conv<BM, BN, BK, 2, NST, WG>(a, stream);
   return launch_conv<BM, BN, BK, 0, NST, WG>(a, stream);
 }
 
@@ -663,6 +669,8 @@ extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int ns
     if (a->bn_relu == 3 && a->bn_mask == nullptr) return -5;
     if (a->bn_relu != 0 && a->bn_relu != 2 && a->bn_relu != 3) return -5;
   }
+  if (a->ldo < a->Cout || a->ldo % 8 != 0) return -6;
+  if ((a->oscale != nullptr || a->ldo != a->Cout) && (a->stats != nullptr || a->addend != nullptr || a->bn_y != nullptr)) return -6;
   if (a->M <= 0) return 0;
   // bm == 256: two wave groups of 128 rows sharing one weight tile
   if (bm == 256 && bn == 128 && bk == 32 && nst == 3) return launch_conv_epi<128, 128, 32, 3, 2>(*a, stream);

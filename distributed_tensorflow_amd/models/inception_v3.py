@@ -255,15 +255,33 @@ class InceptionV3Flower(nn.Module):
     recognition_flower/single/flower_train.py:141-152), so the trunk runs
     without autograd bookkeeping; its batch-norm layers still follow the
     module's train/eval mode like the reference's ``is_training`` flag.
+
+    ``trunk_bn="moving"`` keeps the trunk's batch-norm layers on their moving statistics while training
+    (the usual frozen-feature-extractor setting: the reference never updates those statistics anyway, so
+    its own evaluation pass, ``training=False`` at recognition_flower/single/flower_train.py:188-189, sees
+    features normalised differently from the ones the head was trained on).  Every conv + batch-norm +
+    ReLU of the trunk is then one kernel, with the statistics folded into the convolution epilogue;
+    ``PreLogits`` dropout still follows the train/eval mode.
     """
 
-    def __init__(self, num_classes=5, head_dropout_rate=0.5, act_l2=0.0005):
+    def __init__(self, num_classes=5, head_dropout_rate=0.5, act_l2=0.0005, trunk_bn="batch"):
         super().__init__()
+        if trunk_bn not in ("batch", "moving"):
+            raise ValueError("trunk_bn must be 'batch' or 'moving'")
+        self.trunk_bn = trunk_bn
         self.num_classes = num_classes
         self.trunk = InceptionV3()
         for p in self.trunk.parameters():
             p.requires_grad_(False)
         self.head = FlowerHead(2048, num_classes, dropout_rate=head_dropout_rate, act_l2=act_l2)
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        if self.trunk_bn == "moving":
+            for m in self.trunk.modules():
+                if isinstance(m, ConvBnAct):
+                    m.training = False
+        return self
 
     def forward(self, x):
         with torch.no_grad():

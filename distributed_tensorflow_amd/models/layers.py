@@ -68,10 +68,26 @@ class ConvBnAct(nn.Module):
                                   relu=self.relu, training=self.training, pool_kernel=_pair(kernel),
                                   pool_stride=_pair(stride), pool_padding=padding)
 
+    def _eval_coeffs(self):
+        """(scale, shift) of the running statistics on the device, recomputed only when one of their source
+        tensors has been written or replaced (inference calls this layer thousands of times per restore)."""
+        src = (self.gamma, self.beta, self.running_mean, self.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in src if t is not None)
+        cached = getattr(self, "_coeff_cache", None)
+        if cached is None or cached[0] != key:
+            from ..ops import kernels as K
+            cached = (key, K.bn_eval_coeffs(self.gamma, self.beta, self.running_mean, self.running_var, self.eps))
+            self._coeff_cache = cached
+        return cached[1]
+
     def forward(self, x, residual=None, links=None, out=None):
+        coeffs = None
+        if not self.training and x.is_cuda and not torch.is_grad_enabled():
+            coeffs = self._eval_coeffs()
         return F.conv_bn_act(x, self.weight, self.gamma, self.beta, self.running_mean, self.running_var,
                              stride=self.stride, padding=self.padding, eps=self.eps, momentum=self.momentum,
-                             relu=self.relu, training=self.training, residual=residual, links=links, out=out)
+                             relu=self.relu, training=self.training, residual=residual, links=links, out=out,
+                             eval_coeffs=coeffs)
 
 
 class Conv2d(nn.Module):

@@ -225,7 +225,7 @@ def pick_wgrad_tile(M: int, cout: int, K: int, cin: int = 0) -> Tuple[int, int, 
 # --------------------------------------------------------------------------
 def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, osx, oy0, ox0, isy, isx, B,
                   cin_magic, bias=None, relu=False, stats=False, addend=None, zero_taps=False, addend_mask=None,
-                  bn_tap=None):
+                  bn_tap=None, oscale=None, ldo=0):
     M = B * oyn * oxn
     K = T * cin
     dense_out = osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow
@@ -255,6 +255,8 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     a.T, a.M, a.K = T, M, K
     a.cin_magic = cin_magic
     a.relu = 1 if relu else 0
+    a.oscale = hipk.ptr(oscale)
+    a.ldo = ldo or cout
     a.dense_out = 1 if dense_out else 0
     # 1x1 / stride 1 / no padding: input pixel index == output pixel index, the kernel skips the pixel decode
     a.pointwise = 1 if (zero_taps and a.dense_out and T == 1 and isy == 1 and isx == 1
@@ -265,8 +267,13 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
 
 
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[torch.Tensor] = None,
-             relu: bool = False, want_stats: bool = False):
-    """x [B,IH,IW,Cin] bf16, w [Cout,KH,KW,Cin] bf16 -> (y [B,OH,OW,Cout] bf16, stats partials or None)."""
+             relu: bool = False, want_stats: bool = False, scale: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None):
+    """x [B,IH,IW,Cin] bf16, w [Cout,KH,KW,Cin] bf16 -> (y [B,OH,OW,Cout] bf16, stats partials or None).
+
+    ``scale`` / ``bias`` ([Cout] fp32) turn the epilogue into ``act(conv * scale + bias)`` -- a convolution with
+    its inference-mode batch-norm folded in.  ``out`` is a channel slice ``buf[..., c0:c0+Cout]`` of a contiguous
+    NHWC tensor (``c0`` and the buffer's channel count multiples of 8) that receives the rows directly."""
     hipk.require(x, torch.bfloat16, "x")
     hipk.require(w, torch.bfloat16, "w")
     B = x.shape[0]
@@ -280,12 +287,25 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
             raise ValueError("bias size")
         if want_stats:
             raise ValueError("batch-norm statistics and bias are mutually exclusive")
+    if scale is not None:
+        hipk.require(scale, torch.float32, "scale")
+        if scale.numel() != plan.cout or want_stats:
+            raise ValueError("scale needs Cout entries and excludes batch-norm statistics")
     if B * plan.oh * plan.ow >= 1 << 31:
         raise ValueError("too many output pixels for 32-bit row indices")
-    y = torch.empty((B, plan.oh, plan.ow, plan.cout), dtype=torch.bfloat16, device=x.device)
+    ldo = 0
+    if out is None:
+        y = torch.empty((B, plan.oh, plan.ow, plan.cout), dtype=torch.bfloat16, device=x.device)
+    else:
+        y = out
+        ldo = y.stride(2)
+        if (y.dtype != torch.bfloat16 or y.device != x.device or tuple(y.shape) != (B, plan.oh, plan.ow, plan.cout)
+                or y.stride(3) != 1 or ldo < plan.cout or ldo % 8 or y.stride(1) != plan.ow * ldo
+                or y.stride(0) != plan.oh * plan.ow * ldo or y.data_ptr() % 16 or want_stats):
+            raise ValueError("out must be a 16-byte aligned channel slice of a contiguous NHWC bf16 tensor")
     part = _launch_igemm(x, w, y, plan.fwd_taps, plan.T, plan.ih, plan.iw, plan.cin, plan.oh, plan.ow, plan.cout,
                          plan.oh, plan.ow, 1, 1, 0, 0, plan.sy, plan.sx, B, plan.cin_magic, bias, relu, want_stats,
-                         zero_taps=plan.is_pointwise)
+                         zero_taps=plan.is_pointwise, oscale=scale, ldo=ldo)
     return y, part
 
 

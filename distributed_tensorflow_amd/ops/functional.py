@@ -349,9 +349,13 @@ def conv_bn_act_pool(x, weight, gamma, beta, run_mean, run_var, *, stride, paddi
 
 
 def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, eps, momentum, relu, training,
-                residual=None, links=None, out=None):
+                residual=None, links=None, out=None, eval_coeffs=None):
     """``act(bn(conv(x, weight)) + residual)``; batch statistics when ``training``.
     ``links`` (:class:`Links`) wires the layer's backward pass to its neighbours in a residual block.
+
+    Inference (``training`` false, nothing requiring grad, no residual) on the device is ONE kernel: the
+    normalisation is folded into the convolution's epilogue as a per-channel multiply-add on the fp32
+    accumulators.  ``eval_coeffs`` = cached ``(scale, shift)`` of the running statistics (computed if absent).
 
     ``out`` (device path, nothing requiring grad) is a channel slice of a wider NHWC tensor that
     receives the result directly -- the way parallel branches are concatenated without a copy."""
@@ -362,12 +366,15 @@ def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, e
         if not _use_hip(x) or _needs_grad(x, weight, gamma, beta, residual):
             raise ValueError("out= is a forward-only device path")
         plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], weight.shape[0], kh, kw, sy, sx, pads, x.device)
+        if not training and residual is None:
+            scale, shift = eval_coeffs or K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
+            return cv.conv_fwd(x, weight, plan, bias=shift, relu=relu, scale=scale, out=out)[0]
         y, part = cv.conv_fwd(x, weight, plan, want_stats=training)
         if training:
             _, _, scale, shift = K.bn_finalize(part, y.numel() // plan.cout, eps, gamma, beta, run_mean, run_var,
                                                momentum)
         else:
-            scale, shift = K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
+            scale, shift = eval_coeffs or K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
         return K.bn_apply(y, scale, shift, relu, residual, out=out)
     if not _use_hip(x):
         y = ref.conv2d(x, weight, (sy, sx), pads)
@@ -379,6 +386,9 @@ def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, e
             z = z + residual
         return torch.relu(z) if relu else z
     plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], weight.shape[0], kh, kw, sy, sx, pads, x.device)
+    if not training and residual is None and not _needs_grad(x, weight, gamma, beta):
+        scale, shift = eval_coeffs or K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
+        return cv.conv_fwd(x, weight, plan, bias=shift, relu=relu, scale=scale)[0]
     links = links if links is not None else _NO_LINKS
     if links.input_grad is not None and (plan.dgrad_needs_zero or not x.requires_grad):
         raise ValueError("input_grad needs an input that requires grad and a dgrad that writes every pixel")

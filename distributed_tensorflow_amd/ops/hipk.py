@@ -34,6 +34,7 @@ class ConvArgs(C.Structure):
         ("cin_magic", C.c_uint), ("relu", c_int), ("dense_out", c_int), ("pointwise", c_int),
         ("bn_y", c_void), ("bn_mean", c_void), ("bn_invstd", c_void), ("bn_scale", c_void), ("bn_shift", c_void),
         ("bn_mask", c_void), ("bn_relu", c_int),
+        ("ldo", c_int), ("oscale", c_void),
     ]
 
 

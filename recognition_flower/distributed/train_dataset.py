@@ -55,6 +55,8 @@ flags.DEFINE_integer("image_size", 299, "Network input size.")
 flags.DEFINE_integer("staleness", -1, "Staleness bound (async_ps: -1 = unbounded; async_ssp: delay in steps).")
 flags.DEFINE_float("bucket_mb", 32.0, "Gradient bucket size for the collective modes.")
 flags.DEFINE_float("head_dropout_rate", 0.2, "Drop probability of the head dropout.")
+flags.DEFINE_string("trunk_bn", "batch", "Inception trunk batch-norm while training: batch (statistics of the batch, as the "
+                    "reference's is_training=True) | moving (frozen moving statistics, folded into the convolutions).")
 flags.DEFINE_integer("save_steps", 2, "Checkpoint / summary period in global steps (the reference uses 2).")
 flags.DEFINE_boolean("resume", False, "Restore the latest checkpoint from checkpoint_dir before training.")
 flags.DEFINE_boolean("wipe_checkpoint_dir", False, "ps task 0 deletes checkpoint_dir at start (reference behaviour).")
@@ -146,7 +148,7 @@ def run_worker(spec):
     torch.manual_seed(1234)  # identical initial values on every worker
     model_name = _model_name(device)
     n_classes = _num_classes()
-    kw = {"head_dropout_rate": FLAGS.head_dropout_rate} if model_name == "inception_v3_head" else (
+    kw = {"head_dropout_rate": FLAGS.head_dropout_rate, "trunk_bn": FLAGS.trunk_bn} if model_name == "inception_v3_head" else (
         {"dropout_rate": FLAGS.head_dropout_rate} if model_name == "flower_cnn" else {})
     model = build_model(model_name, num_classes=n_classes, device=device, **kw)
 

@@ -47,6 +47,8 @@ flags.DEFINE_string("model", "auto", "inception_v3_head | flower_cnn | resnet50 
 flags.DEFINE_integer("batch_size", 32, "Training batch size (the reference hard-codes 32).")
 flags.DEFINE_float("learning_rate", 0.001, "Initial learning rate of the exponential decay schedule.")
 flags.DEFINE_float("head_dropout_rate", 0.5, "Drop probability of the head dropout (the reference feeds 0.5).")
+flags.DEFINE_string("trunk_bn", "batch", "Inception trunk batch-norm while training: batch (statistics of the batch, as the "
+                    "reference's is_training=True) | moving (frozen moving statistics, folded into the convolutions).")
 flags.DEFINE_string("device", "auto", "cuda | cpu | auto")
 flags.DEFINE_integer("max_steps", 0, "Stop after this many steps (0 = n_epochs * iterations per epoch).")
 flags.DEFINE_integer("seed", 42, "Random seed.")
@@ -87,7 +89,7 @@ def main(argv):
 
     batch_size = min(FLAGS.batch_size, len(train))
     n_iterations_per_epoch = max(1, len(train) // batch_size)
-    kw = {"head_dropout_rate": FLAGS.head_dropout_rate} if model_name == "inception_v3_head" else (
+    kw = {"head_dropout_rate": FLAGS.head_dropout_rate, "trunk_bn": FLAGS.trunk_bn} if model_name == "inception_v3_head" else (
         {"dropout_rate": FLAGS.head_dropout_rate} if model_name == "flower_cnn" else {})
     model = build_model(model_name, num_classes=len(flower_classes), device=device, **kw)
     engine = DataParallelEngine(model, mode="sync_dp", optimizer="adam",

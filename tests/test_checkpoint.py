@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from distributed_tensorflow_amd.io import bundle
@@ -236,3 +237,20 @@ def test_saved_model_pb_carries_tags_saver_collections_and_signatures(tmp_path):
     assert pi.method_name == "tensorflow/serving/predict" and [d.size for d in pi.inputs["images"].tensor_shape.dim] == [-1]
     assert pi.outputs["scores"].dtype == 1 and [d.size for d in pi.outputs["scores"].tensor_shape.dim] == [-1, 1]
     assert pi.outputs["classes"].dtype == 7
+
+
+def test_trunk_bn_moving_keeps_trunk_normalisation_frozen():
+    """``trunk_bn="moving"``: train() leaves the trunk's conv+bn layers on their moving statistics (and does not
+    update them), PreLogits dropout and the head still follow the mode; the variable set is unchanged."""
+    from distributed_tensorflow_amd.models.layers import ConvBnAct
+
+    m = build_model("inception_v3_head", trunk_bn="moving").train()
+    layers = [x for x in m.trunk.modules() if isinstance(x, ConvBnAct)]
+    assert len(layers) == 96 and not any(x.training for x in layers)  # 94 executed + 2 AuxLogits (variables only)
+    assert m.trunk.training and m.head.training
+    m.eval()
+    assert not m.trunk.training and not any(x.training for x in layers)
+    ref_names = {v.name for v in model_variables(build_model("inception_v3_head"))}
+    assert {v.name for v in model_variables(m)} == ref_names
+    with pytest.raises(ValueError):
+        build_model("inception_v3_head", trunk_bn="frozen")

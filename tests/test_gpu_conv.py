@@ -69,6 +69,31 @@ def test_conv_bias_relu(case):
 
 
 @pytest.mark.parametrize("case", CASES)
+def test_conv_folded_batchnorm_into_channel_slice(case):
+    """Inference epilogue: relu(conv * scale + shift) on the fp32 accumulators, written into a channel slice of a
+    wider NHWC buffer whose other channels stay untouched."""
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case, 4)
+    xb, wb = x.bfloat16(), w.bfloat16()
+    g = torch.Generator().manual_seed(5)
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    want = torch.relu(ref.conv2d(xb.float(), wb.float(), (sy, sx), pads) * scale + shift)
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    y, part = cv.conv_fwd(xb.cuda(), wb.cuda(), plan, bias=shift.cuda(), relu=True, scale=scale.cuda())
+    assert part is None
+    torch.testing.assert_close(y.float().cpu(), want, rtol=2e-2, atol=2e-2)
+    buf = torch.full((B, plan.oh, plan.ow, 16 + Cout + 24), 7.0, dtype=torch.bfloat16, device="cuda")
+    out, _ = cv.conv_fwd(xb.cuda(), wb.cuda(), plan, bias=shift.cuda(), relu=True, scale=scale.cuda(),
+                         out=buf[..., 16:16 + Cout])
+    torch.cuda.synchronize()
+    assert out.data_ptr() == buf[..., 16:].data_ptr()
+    assert torch.equal(buf[..., 16:16 + Cout], y)
+    assert (buf[..., :16] == 7).all() and (buf[..., 16 + Cout:] == 7).all()
+    with pytest.raises(ValueError):
+        cv.conv_fwd(xb.cuda(), wb.cuda(), plan, bias=shift.cuda(), out=buf[..., 4:4 + Cout])  # not 16-byte aligned
+
+
+@pytest.mark.parametrize("case", CASES)
 def test_conv_backward(case):
     B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
     x, w, pads = _mk(case, 2)

@@ -68,6 +68,43 @@ def test_forward_backward_matches_cpu_reference(name, size, batch):
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("name,size,batch", [("flower_cnn", 64, 8), ("resnet50", 96, 8), ("inception_v3_head", 299, 2)])
+def test_inference_forward_matches_cpu_reference(name, size, batch):
+    """Eval mode: running statistics folded into the convolution epilogues (one kernel per conv+bn+relu layer)
+    against the fp32 CPU definition of the same network."""
+    torch.manual_seed(1)
+    cpu = build_model(name, device="cpu").eval()
+    g = torch.Generator().manual_seed(2)
+    for n, b in cpu.named_buffers():
+        if n.endswith("running_mean"):
+            b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+        elif n.endswith("running_var"):
+            b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+    for p in cpu.parameters():
+        if p.dim() > 1:
+            p.data = p.data.bfloat16().float()
+    gpu = cast_for_device(copy.deepcopy(cpu), "cuda").eval()
+    x, _ = _images(batch, size, seed=3)
+    xb = x.bfloat16()
+    with torch.no_grad():
+        want = cpu(xb.float())
+        got = gpu(xb.cuda())
+        again = gpu(xb.cuda())  # second call: cached (scale, shift)
+    want = (want[0] if isinstance(want, tuple) else want)[:, :5].float()
+    got_l = (got[0] if isinstance(got, tuple) else got)[:, :5].float().cpu()
+    assert torch.equal(got_l, (again[0] if isinstance(again, tuple) else again)[:, :5].float().cpu())
+    scale = want.abs().max().item() + 1e-3
+    assert (got_l - want).abs().max().item() <= 0.05 * scale, ((got_l - want).abs().max().item(), scale)
+    # restoring other statistics invalidates the cached coefficients
+    for n, b in gpu.named_buffers():
+        if n.endswith("running_var"):
+            b.mul_(4.0)
+    with torch.no_grad():
+        changed = gpu(xb.cuda())
+    changed = (changed[0] if isinstance(changed, tuple) else changed)[:, :5].float().cpu()
+    assert not torch.equal(changed, got_l)
+
+
 def test_resnet50_loss_decreases_on_fixed_batch():
     torch.manual_seed(0)
     model = build_model("resnet50", device="cuda").train()
