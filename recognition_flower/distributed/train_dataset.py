@@ -68,6 +68,8 @@ flags.DEFINE_string("profile_dir", "", "Write a torch.profiler Chrome trace of a
 flags.DEFINE_boolean("hip_graph", False, "collective modes on GPU: replay the step (including its collectives) from a HIP graph")
 flags.DEFINE_string("fault_inject", "", "Testing hook: 'exit_at_step:N' makes this worker die abruptly at global step N.")
 flags.DEFINE_boolean("shutdown_ps", True, "The chief stops the ps tasks when it finishes (the reference's ps never exits).")
+flags.DEFINE_float("collective_timeout", 600.0, "Collective modes: seconds a rank waits inside a collective before the job "
+                   "aborts (a lost rank must end the job so that a restart with --resume can take over).")
 flags.DEFINE_float("worker_timeout", 30.0, "Seconds of silence after which a worker no longer counts for the staleness bound.")
 
 FLAGS = flags.FLAGS
@@ -166,7 +168,10 @@ def run_worker(spec):
         if world > 1 and not dist.is_initialized():
             if tr is None:
                 os.environ.update(rendezvous_from_cluster(spec))
-            dist.init_process_group("nccl" if device.type == "cuda" else "gloo", rank=task_index, world_size=world)
+            import datetime
+
+            dist.init_process_group("nccl" if device.type == "cuda" else "gloo", rank=task_index, world_size=world,
+                                    timeout=datetime.timedelta(seconds=FLAGS.collective_timeout))
         mode = "sync_dp" if FLAGS.mode == "async_ps" else FLAGS.mode
         engine = DataParallelEngine(model, mode=mode, optimizer="adam", lr=params["learning_rate"],
                                     bucket_mb=FLAGS.bucket_mb, staleness=max(FLAGS.staleness, 0),

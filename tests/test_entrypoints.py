@@ -165,3 +165,34 @@ def test_collective_mode_via_tf_config_workers(tmp_path):
     assert [p.returncode for p in procs] == [0, 0, 0], outs
     assert "nothing to serve" in outs[0]
     assert int(bundle.read_bundle(bundle.latest_checkpoint(str(tmp_path / "ckpt")))["global_step"]) == 4
+
+
+def test_collective_mode_lost_rank_ends_the_job_and_resume_continues(tmp_path):
+    """sync_dp over two workers: one rank dies at step 3 (fault hook); the survivor must fail instead of waiting
+    for ever, and a relaunch with --resume continues from the last checkpoint to the step budget."""
+    import socket
+
+    def port():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+    def launch(extra):
+        cluster = {"worker": ["localhost:%d" % port(), "localhost:%d" % port()]}
+        common = ["train_dataset.py", "--synthetic", "--mode=sync_dp", "--checkpoint_dir=%s/ckpt/" % tmp_path,
+                  "--summaries_dir=%s/events/" % tmp_path, "--train_steps=8", "--batch_size=4", "--image_size=32",
+                  "--collective_timeout=20"]
+        procs = []
+        for i in range(2):
+            env = dict(os.environ, TF_CONFIG=json.dumps({"cluster": cluster, "task": {"type": "worker", "index": i}}))
+            procs.append(subprocess.Popen([sys.executable] + common + extra[i], cwd=DIST, env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=240)[0] for p in procs]
+        return [p.returncode for p in procs], outs
+
+    codes, outs = launch([[], ["--fault_inject=exit_at_step:3"]])
+    assert codes[1] == 17 and codes[0] != 0, outs
+    saved = int(bundle.read_bundle(bundle.latest_checkpoint(str(tmp_path / "ckpt")))["global_step"])
+    assert 2 <= saved <= 4
+    codes, outs = launch([["--resume"], ["--resume"]])
+    assert codes == [0, 0], outs
+    assert "resumed from global step %d" % saved in outs[0]
+    assert int(bundle.read_bundle(bundle.latest_checkpoint(str(tmp_path / "ckpt")))["global_step"]) == 8
