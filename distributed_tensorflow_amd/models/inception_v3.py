@@ -38,17 +38,24 @@ def _concat(block: nn.Module, x, hw, parts):
     ``parts`` is a list of ``(channels, producer)``; ``producer(out)`` computes one branch and, when
     ``out`` (a channel slice of the result) is given, has its last layer write into it.  With nothing
     requiring grad (the frozen trunk of the flower model) the branches write straight into one
-    buffer; otherwise the outputs are joined with ``torch.cat`` so autograd sees ordinary tensors."""
+    buffer -- side by side on separate HIP streams when the batch is small; otherwise the outputs are joined with ``torch.cat`` so autograd sees ordinary tensors."""
     if not F.concat_plan(x, *block.parameters()):
         return torch.cat([prod(None) for _, prod in parts], dim=3)
     buf = torch.empty((x.shape[0], hw[0], hw[1], sum(c for c, _ in parts)), dtype=x.dtype, device=x.device)
-    off = 0
+
+    def job(sl, prod):
+        def run():
+            r = prod(sl)
+            if r.data_ptr() != sl.data_ptr():  # producer without a fused writer (pooling branch)
+                sl.copy_(r)
+        return run
+
+    jobs, off = [], 0
     for c, prod in parts:
-        sl = buf[..., off:off + c]
-        r = prod(sl)
-        if r.data_ptr() != sl.data_ptr():  # producer without a fused writer (pooling branch)
-            sl.copy_(r)
+        jobs.append(job(buf[..., off:off + c], prod))
         off += c
+    # the branches only share their input; at small batches they run on separate streams (F.run_branches)
+    F.run_branches(x, jobs)
     return buf
 
 

@@ -20,6 +20,8 @@ returned to autograd in the parameter's dtype.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 import torch
@@ -149,6 +151,51 @@ class Links:
 
 
 _NO_LINKS = Links()
+
+
+# Independent branches of a block on separate HIP streams.  At small batches one convolution of an Inception
+# branch is a few hundred workgroups at most -- one partial wave over the 256 CUs, ~20 us of mostly latency --
+# so the four branches of a block are enqueued on four streams and run side by side; captured in a HIP graph
+# the fork / join events become parallel graph branches (measured, Inception-v3 head training: +25 % at batch
+# 32, +9 % at batch 256; serving 2.36 -> 1.82 ms at batch 1).  Eager launches at such sizes are bound by the
+# host enqueueing kernels, where switching streams only adds cost (-24 % at batch 32), so by default the fork
+# happens only while a graph is being captured (DTFA_BRANCH_PARALLEL=always|capture|never).  Above
+# ``BRANCH_PARALLEL_MAX_ROWS`` rows per layer every kernel fills the chip on its own and the branches stay on
+# one stream.
+BRANCH_PARALLEL = os.environ.get("DTFA_BRANCH_PARALLEL", "capture")
+BRANCH_PARALLEL_MAX_ROWS = int(os.environ.get("DTFA_BRANCH_PARALLEL_MAX_ROWS", str(1 << 20)))
+_branch_streams: dict = {}
+
+
+def branch_streams(device, n: int):
+    key = torch.device(device).index
+    pool = _branch_streams.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+def run_branches(x: torch.Tensor, jobs) -> None:
+    """Run the callables ``jobs`` (each enqueues device work that reads ``x`` and writes memory of its own).
+    While a HIP graph is being captured (and the tensors have few enough rows for the kernels not to fill the
+    chip one by one): job 0 stays on the current stream, the others fork onto side streams and are joined back
+    before returning.  Otherwise plain sequential calls."""
+    rows = x.shape[0] * x.shape[1] * x.shape[2] if x.dim() == 4 else 0
+    parallel = (x.is_cuda and len(jobs) > 1 and 0 < rows <= BRANCH_PARALLEL_MAX_ROWS and BRANCH_PARALLEL != "never"
+                and (BRANCH_PARALLEL == "always" or torch.cuda.is_current_stream_capturing()))
+    if not parallel:
+        for job in jobs:
+            job()
+        return
+    cur = torch.cuda.current_stream(x.device)
+    fork = cur.record_event()
+    side = branch_streams(x.device, len(jobs) - 1)
+    jobs[0]()
+    for st, job in zip(side, jobs[1:]):
+        st.wait_event(fork)
+        with torch.cuda.stream(st):
+            job()
+        cur.wait_event(st.record_event())
 
 
 # ----------------------------------------------------------------------------

@@ -187,3 +187,34 @@ def test_inception_branch_slices_equal_concat(monkeypatch):
         joined = model.trunk(x)
     assert direct.shape == joined.shape == (4, 2048)
     assert torch.equal(direct, joined)
+
+
+def test_inception_branches_on_streams_equal_sequential(monkeypatch):
+    """Branches of the Inception blocks enqueued on separate HIP streams (forced here outside graph capture, and
+    captured + replayed) give the bits of the one-stream forward, in batch-statistics and in moving-statistics mode."""
+    torch.manual_seed(0)
+    x, _ = _images(4, 299, seed=6)
+    x = x.cuda().bfloat16()
+    for mode in ("train", "eval"):
+        model = getattr(build_model("inception_v3_head", device="cuda"), mode)()
+
+        def last_block():  # (PreLogits sits behind a dropout that draws a new mask per call in train mode)
+            return dict(model.trunk.endpoints(x, fuse_pools=True))["Mixed_7c"]
+
+        with torch.no_grad():
+            monkeypatch.setattr(F, "BRANCH_PARALLEL", "never")
+            seq = last_block()
+            monkeypatch.setattr(F, "BRANCH_PARALLEL", "always")
+            par = last_block()
+            torch.cuda.synchronize()
+            assert seq.shape == (4, 8, 8, 2048) and torch.equal(seq, par)
+            monkeypatch.setattr(F, "BRANCH_PARALLEL", "capture")
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = last_block()
+                graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(seq, out)
