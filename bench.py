@@ -123,9 +123,12 @@ def main():
                     help="inception_v3_head: trunk batch-norm on batch statistics (reference) or frozen moving statistics")
     ap.add_argument("--also", default="flower_cnn",
                     help="second model measured after the headline one and reported under \"also\" ('' = none)")
-    ap.add_argument("--hip_graph", type=int, default=0,
-                    help="1: record the whole step (fwd, bwd, collectives, optimizer) in a HIP graph and replay it")
+    ap.add_argument("--hip_graph", type=int, default=-1,
+                    help="1: record the whole step (fwd, bwd, collectives, optimizer) in a HIP graph and replay it; "
+                         "default: on for inception_v3_head (hundreds of short kernels per step), off otherwise")
     args = ap.parse_args()
+    if args.hip_graph < 0:
+        args.hip_graph = 1 if args.model == "inception_v3_head" else 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
