@@ -196,3 +196,20 @@ def test_collective_mode_lost_rank_ends_the_job_and_resume_continues(tmp_path):
     assert codes == [0, 0], outs
     assert "resumed from global step %d" % saved in outs[0]
     assert int(bundle.read_bundle(bundle.latest_checkpoint(str(tmp_path / "ckpt")))["global_step"]) == 8
+
+
+def test_run_sh_launches_ps_and_workers(tmp_path):
+    """The local launcher starts one ps and N workers (the reference's run.sh started worker 0 twice and no ps,
+    recognition_flower/distributed/run.sh:3-6) and returns when training is done."""
+    import socket
+
+    def port():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+    env = dict(os.environ, PS_PORT=str(port()), WORKER_PORT0=str(port()))
+    r = subprocess.run(["bash", "run.sh", "2", "--synthetic", "--model=flower_cnn", "--image_size=32", "--batch_size=4",
+                        "--train_steps=6", "--checkpoint_dir=%s/ckpt/" % tmp_path, "--summaries_dir=%s/events/" % tmp_path],
+                       cwd=DIST, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count("finished training") == 2
+    assert int(bundle.read_bundle(bundle.latest_checkpoint(str(tmp_path / "ckpt")))["global_step"]) >= 6
