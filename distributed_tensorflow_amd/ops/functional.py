@@ -89,10 +89,58 @@ def _deliver_small(param, grad: Optional[torch.Tensor]):
     return None
 
 
+# Weight gradients on a side stream.  In the backward pass the weight gradient of a layer is off the critical
+# path (nothing downstream reads it before the optimizer / the bucket's collective), while the data gradient
+# and the batch-norm backward of the next layer are on it.  With DTFA_WGRAD_STREAM=1 every weight-gradient
+# kernel that writes into the flat gradient buffer is enqueued on one side stream per device, behind an event
+# of the main stream, and the main stream joins it where the gradients are consumed (`join_wgrad_stream`).
+# Measured on ResNet-50 at batch 2048 and the flower CNN at batch 1024: 13.1 -> 13.1 .. 13.3 k img/s and
+# 65.9 -> 66.0 k img/s for depths 2 .. 16, i.e. within run-to-run noise -- at these sizes every kernel fills
+# the chip by itself and a second stream only fills tile-quantisation tails.  Off by default.
+# The operands of an in-flight weight gradient are kept referenced (not ``record_stream``-ed: blocks marked that
+# way return to the allocator only after an event query, and at tens of GB of activations the allocator then
+# falls back to hipMalloc / hipFree, which cost 5x in step time when tried) until the main stream has been made
+# to wait for the kernel; at most ``WGRAD_DEPTH`` layers are in flight, which bounds the memory held back.
+WGRAD_STREAM = os.environ.get("DTFA_WGRAD_STREAM", "0") == "1"
+WGRAD_DEPTH = int(os.environ.get("DTFA_WGRAD_DEPTH", "2"))
+_wgrad_streams: dict = {}
+_wgrad_pending: dict = {}   # device index -> list of (event, x, dy) in issue order
+
+
+def _wgrad_stream(device):
+    key = torch.device(device).index
+    st = _wgrad_streams.get(key)
+    if st is None:
+        st = _wgrad_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_wgrad_stream(device) -> None:
+    """Make the current stream wait for every weight-gradient kernel enqueued on the side stream so far."""
+    key = torch.device(device).index
+    q = _wgrad_pending.get(key)
+    if q:
+        torch.cuda.current_stream(device).wait_event(q[-1][0])  # one stream: the last event covers all before it
+        q.clear()
+
+
 def _deliver_wgrad(param, x, dy, plan):
     mg = getattr(param, "main_grad", None)
     if mg is not None:
-        cv.conv_wgrad(x, dy, plan, out=mg, accumulate=getattr(param, "_grad_filled", False))
+        acc = getattr(param, "_grad_filled", False)
+        if WGRAD_STREAM and x.is_cuda:
+            st = _wgrad_stream(x.device)
+            cur = torch.cuda.current_stream(x.device)
+            q = _wgrad_pending.setdefault(x.device.index, [])
+            while len(q) >= WGRAD_DEPTH:   # oldest in-flight layer: the main stream waits for it, its operands go
+                cur.wait_event(q.pop(0)[0])
+            st.wait_event(cur.record_event())
+            with torch.cuda.stream(st):
+                cv.conv_wgrad(x, dy, plan, out=mg, accumulate=acc)
+                done = st.record_event()
+            q.append((done, x, dy))
+        else:
+            cv.conv_wgrad(x, dy, plan, out=mg, accumulate=acc)
         _notify(param)
         return None
     out = torch.empty(param.shape, dtype=param.dtype, device=param.device)

@@ -150,9 +150,19 @@ class DataParallelEngine:
         self.flat.begin_step()
         self._handles = []
 
+    def _join_side_streams(self) -> None:
+        # weight-gradient kernels may run on a side stream (ops.functional.WGRAD_STREAM): whoever consumes the
+        # flat gradient buffer -- a collective, the optimizer -- first makes the current stream wait for them
+        dev = self.flat.device
+        if dev.type == "cuda":
+            from ..ops import functional as F
+
+            F.join_wgrad_stream(dev)
+
     def _on_bucket_ready(self, b: Bucket) -> None:
         if not self.collective:
             return
+        self._join_side_streams()
         g = b.group
         grad = g.grad[b.start:b.end]
         if self.mode == "sync_dp" or (self.mode == "async_ssp" and self.staleness == 0):
@@ -204,6 +214,7 @@ class DataParallelEngine:
         if prepared and not self.graph_capturable:
             raise ValueError("async_ssp with staleness > 0 rotates buffers per step and cannot be captured")
         self.flat.collect_autograd_grads()
+        self._join_side_streams()
         scale = 1.0 / self.world
         if self.mode == "sharded_ps":
             if not self.collective:
