@@ -55,9 +55,11 @@ class PSStopped(ConnectionError):
     """The parameter server is shutting down (the chief finished the step budget)."""
 
 
-def _recv_exact(sock: socket.socket, n: int) -> bytearray:
-    buf = bytearray(n)
-    view = memoryview(buf)
+def _recv_exact(sock: socket.socket, n: int, into=None):
+    """``n`` bytes from the socket, into ``into`` (a writable byte buffer of at least ``n`` bytes, e.g. pinned
+    staging memory) or a new bytearray."""
+    buf = bytearray(n) if into is None or len(into) < n else into
+    view = memoryview(buf)[:n]
     got = 0
     while got < n:
         k = sock.recv_into(view[got:], n - got)
@@ -67,18 +69,31 @@ def _recv_exact(sock: socket.socket, n: int) -> bytearray:
     return buf
 
 
-def _send_msg(sock, op, worker=0, status=0, clock=0, payload: bytes = b""):
-    sock.sendall(HEADER.pack(MAGIC, op, worker, status, clock, len(payload)))
-    if payload:
-        sock.sendall(payload)
+def _send_msg(sock, op, worker=0, status=0, clock=0, payload=b""):
+    """``payload``: bytes or any C-contiguous buffer (numpy array, memoryview); sent without an intermediate copy."""
+    view = memoryview(payload).cast("B") if not isinstance(payload, (bytes, bytearray)) else payload
+    sock.sendall(HEADER.pack(MAGIC, op, worker, status, clock, len(view)))
+    if len(view):
+        sock.sendall(view)
 
 
-def _recv_msg(sock):
+def _recv_msg(sock, into=None):
     magic, op, worker, status, clock, n = HEADER.unpack(bytes(_recv_exact(sock, HEADER.size)))
     if magic != MAGIC:
         raise ConnectionError("bad magic")
-    payload = _recv_exact(sock, n) if n else bytearray()
+    payload = _recv_exact(sock, n, into) if n else bytearray()
+    if into is not None and payload is into:
+        payload = memoryview(into)[:n]
     return op, worker, status, clock, payload
+
+
+def _big_buffers(sock) -> None:
+    # variable / gradient messages are megabytes: fewer, larger kernel copies per message
+    for opt in (socket.SO_SNDBUF, socket.SO_RCVBUF):
+        try:
+            sock.setsockopt(socket.SOL_SOCKET, opt, 4 << 20)
+        except OSError:
+            pass
 
 
 # ----------------------------------------------------------------------------
@@ -148,6 +163,7 @@ class ParameterServer:
         worker = -1
         try:
             conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            _big_buffers(conn)
             while True:
                 op, worker, _, clock, payload = _recv_msg(conn)
                 now = time.time()
@@ -196,7 +212,7 @@ class ParameterServer:
                     if not self.initialized:
                         _send_msg(conn, op, worker, ST_NOT_INIT, 0)
                         continue
-                    g = torch.from_numpy(np.frombuffer(payload, dtype=np.float32).copy())
+                    g = torch.from_numpy(np.frombuffer(payload, dtype=np.float32))  # the receive buffer itself
                     with self.lock:
                         if g.numel() != self.params.numel():
                             _send_msg(conn, op, worker, ST_ERROR, 0)
@@ -342,11 +358,13 @@ class _Conn:
                 time.sleep(0.1)
         self.sock.settimeout(None)
         self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        _big_buffers(self.sock)
         self.worker = worker
 
-    def call(self, op, clock=0, payload: bytes = b""):
+    def call(self, op, clock=0, payload=b"", into=None):
+        """``into``: byte buffer that receives the reply's payload when it fits (no allocation, no copy)."""
         _send_msg(self.sock, op, self.worker, 0, clock, payload)
-        rop, _, status, rclock, data = _recv_msg(self.sock)
+        rop, _, status, rclock, data = _recv_msg(self.sock, into)
         if rop != op:
             raise ConnectionError("protocol error: reply %d to request %d" % (rop, op))
         return status, rclock, data
@@ -372,7 +390,9 @@ class PSWorkerEngine:
         self.is_chief = is_chief
         self.flat = FlatParams(model, bucket_mb=1 << 20)  # one bucket per group: no collectives here
         self.lr = lr
+        self.mode = "async_ps"
         self.clock = 0
+        self._prepared = False
         self.global_step = initial_global_step
         self.optimizer = self  # exposes current_lr() to the session
         self._optimizer_name, self._opt_kwargs = optimizer, dict(opt_kwargs or {})
@@ -385,6 +405,13 @@ class PSWorkerEngine:
         self.placement: List[List[Tuple[object, object]]] = [[] for _ in ps_addresses]
         for i, gs in enumerate(segs):
             self.placement[i % len(ps_addresses)].append(gs)
+        # one host staging buffer per ps task, page-locked when the model lives on a GPU: gradients are gathered
+        # into it with asynchronous device-to-host copies and sent from it, variables are received into it and
+        # uploaded from it -- no intermediate byte strings
+        pin = self.flat.device.type == "cuda"
+        self._stage = [torch.empty(sum(s.numel for _, s in pl), dtype=torch.float32, pin_memory=pin)
+                       for pl in self.placement]
+        self._stage_np = [t.numpy() for t in self._stage]
         self.conns = [_Conn(h, p, worker_index, connect_timeout) for h, p in ps_addresses]
         for c in self.conns:
             c.call(OP_HELLO, 0)
@@ -392,7 +419,7 @@ class PSWorkerEngine:
             for i, c in enumerate(self.conns):
                 meta = json.dumps({"optimizer": optimizer, "lr": lr, "opt_kwargs": self._opt_kwargs,
                                    "global_step": initial_global_step}).encode()
-                c.call(OP_INIT, 0, struct.pack("<I", len(meta)) + meta + self._pack(i, "master"))
+                c.call(OP_INIT, 0, struct.pack("<I", len(meta)) + meta + self._pack(i, "master").tobytes())
         else:
             for c in self.conns:
                 st, _, _ = c.call(OP_WAIT_INIT, 0)
@@ -404,26 +431,37 @@ class PSWorkerEngine:
         return self.lr
 
     # -- (un)packing -------------------------------------------------------------
-    def _pack(self, ps: int, what: str) -> bytes:
-        parts = []
+    def _pack(self, ps: int, what: str):
+        """The segments placed on ps task ``ps`` gathered into its staging buffer; returns that buffer (numpy)."""
+        stage, pos = self._stage[ps], 0
         for g, s in self.placement[ps]:
             src = g.master if what == "master" else g.grad
-            parts.append(src[s.offset:s.offset + s.numel].detach().float().cpu().numpy().tobytes())
-        return b"".join(parts)
+            stage[pos:pos + s.numel].copy_(src[s.offset:s.offset + s.numel].detach(), non_blocking=True)
+            pos += s.numel
+        if stage.is_pinned():
+            torch.cuda.current_stream(self.flat.device).synchronize()
+        return self._stage_np[ps]
 
     def _unpack_params(self, ps: int, data) -> None:
-        arr = np.frombuffer(data, dtype=np.float32)
+        """``data``: the reply payload -- a view of this ps task's staging buffer when it was received in place."""
+        n = len(data) // 4
+        if n != self._stage[ps].numel():
+            raise ConnectionError("ps %d returned %d values, expected %d" % (ps, n, self._stage[ps].numel()))
+        stage = self._stage[ps]
+        if not isinstance(data, memoryview):
+            stage.copy_(torch.from_numpy(np.frombuffer(data, dtype=np.float32)))
         pos = 0
         for g, s in self.placement[ps]:
-            g.master[s.offset:s.offset + s.numel].copy_(torch.from_numpy(arr[pos:pos + s.numel].copy()))
+            g.master[s.offset:s.offset + s.numel].copy_(stage[pos:pos + s.numel], non_blocking=True)
             pos += s.numel
-        if pos != arr.size:
-            raise ConnectionError("ps %d returned %d values, expected %d" % (ps, arr.size, pos))
 
     # -- protocol ---------------------------------------------------------------
     def pull(self) -> None:
+        if self._stage[0].is_pinned():
+            # uploads of an earlier pull may still be reading the staging buffers
+            torch.cuda.current_stream(self.flat.device).synchronize()
         for i, c in enumerate(self.conns):
-            st, step, data = c.call(OP_PULL, self.clock)
+            st, step, data = c.call(OP_PULL, self.clock, into=memoryview(self._stage_np[i]).cast("B"))
             if st == ST_STOPPED:
                 raise PSStopped("parameter server is shutting down")
             if st != ST_OK:
@@ -436,10 +474,33 @@ class PSWorkerEngine:
 
     def begin_step(self) -> None:
         self.flat.begin_step()
+        if self._prepared:  # the pull was done by prepare_step (step-graph protocol)
+            self._prepared = False
+            return
         self.pull()
 
-    def finish_step(self) -> int:
+    # Step-graph protocol (train/graph.py): the device part of a worker step -- forward, backward, gradients
+    # into the flat buffer -- is captured once and replayed; the network parts stay on the host around it:
+    # ``prepare_step`` pulls the variables before the replay, ``advance_step`` pushes the gradients after it.
+    @property
+    def graph_capturable(self) -> bool:
+        return self.flat.device.type == "cuda"
+
+    def prepare_step(self) -> None:
+        self.pull()
+        self._prepared = True
+
+    def advance_step(self) -> int:
+        self._prepared = False
+        return self._push()
+
+    def finish_step(self, prepared: bool = False) -> int:
         self.flat.collect_autograd_grads()
+        if prepared:  # inside a graph capture: the push follows the replay (advance_step)
+            return self.global_step
+        return self._push()
+
+    def _push(self) -> int:
         for i, c in enumerate(self.conns):
             st, step, _ = c.call(OP_PUSH, self.clock, self._pack(i, "grad"))
             if st == ST_STOPPED:
@@ -515,7 +576,7 @@ class PSWorkerEngine:
         """Push restored master values (``FlatGroup.master``) back to the ps tasks."""
         for i, c in enumerate(self.conns):
             meta = json.dumps({"slots": [], "global_step": self.global_step}).encode()
-            c.call(OP_SET_STATE, self.clock, struct.pack("<I", len(meta)) + meta + self._pack(i, "master"))
+            c.call(OP_SET_STATE, self.clock, struct.pack("<I", len(meta)) + meta + self._pack(i, "master").tobytes())
         for g in self.flat.groups:
             g.sync_compute_from_master()
 

@@ -65,7 +65,8 @@ flags.DEFINE_boolean("legacy_bgr_input", False, "Feed BGR [0,255] pixels like th
 flags.DEFINE_string("device", "auto", "cuda | cpu | auto")
 flags.DEFINE_integer("p2p_small_kb", 0, "sync_dp on GPUs: gradient buckets up to this size use the one-shot xGMI mailbox all-reduce instead of RCCL (0 = off)")
 flags.DEFINE_string("profile_dir", "", "Write a torch.profiler Chrome trace of a few steps here (empty = off).")
-flags.DEFINE_boolean("hip_graph", False, "collective modes on GPU: replay the step (including its collectives) from a HIP graph")
+flags.DEFINE_boolean("hip_graph", False, "on a GPU: replay the device part of the step from a HIP graph (collective modes: including "
+                     "the collectives; async_ps: forward + backward, with the pull before and the push after the replay)")
 flags.DEFINE_string("fault_inject", "", "Testing hook: 'exit_at_step:N' makes this worker die abruptly at global step N.")
 flags.DEFINE_boolean("shutdown_ps", True, "The chief stops the ps tasks when it finishes (the reference's ps never exits).")
 flags.DEFINE_float("collective_timeout", 600.0, "Collective modes: seconds a rank waits inside a collective before the job "
