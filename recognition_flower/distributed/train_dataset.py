@@ -65,8 +65,9 @@ flags.DEFINE_boolean("legacy_bgr_input", False, "Feed BGR [0,255] pixels like th
 flags.DEFINE_string("device", "auto", "cuda | cpu | auto")
 flags.DEFINE_integer("p2p_small_kb", 0, "sync_dp on GPUs: gradient buckets up to this size use the one-shot xGMI mailbox all-reduce instead of RCCL (0 = off)")
 flags.DEFINE_string("profile_dir", "", "Write a torch.profiler Chrome trace of a few steps here (empty = off).")
-flags.DEFINE_boolean("hip_graph", False, "on a GPU: replay the device part of the step from a HIP graph (collective modes: including "
-                     "the collectives; async_ps: forward + backward, with the pull before and the push after the replay)")
+flags.DEFINE_string("hip_graph", "auto", "on a GPU: replay the device part of the step from a HIP graph -- true | false | auto "
+                    "(auto: on for async_ps, where the graph holds forward + backward and the pull / push stay on the host around "
+                    "it; off for the collective modes, whose graph would hold the collectives as well)")
 flags.DEFINE_string("fault_inject", "", "Testing hook: 'exit_at_step:N' makes this worker die abruptly at global step N.")
 flags.DEFINE_boolean("shutdown_ps", True, "The chief stops the ps tasks when it finishes (the reference's ps never exits).")
 flags.DEFINE_float("collective_timeout", 600.0, "Collective modes: seconds a rank waits inside a collective before the job "
@@ -200,7 +201,7 @@ def run_worker(spec):
     # the reference scales the activity regulariser by 0.01 in this script (train_dataset.py:159-160)
     sess = TrainingSession(model, engine, num_classes=n_classes, hooks=hooks, is_chief=is_chief, reg_weight=0.01,
                            logits_act_l2=0.01 * head_l2, global_step=start_step,
-                           hip_graph=FLAGS.hip_graph and device.type == "cuda")
+                           hip_graph=_want_hip_graph() and device.type == "cuda")
     data = train_input_fn(FLAGS.tfrecords_path, params, device, task_index, world)
     fault_step = int(FLAGS.fault_inject.split(":")[1]) if FLAGS.fault_inject.startswith("exit_at_step:") else None
     t0 = time.time()
@@ -230,6 +231,17 @@ def run_worker(spec):
     if hasattr(data, "close"):
         data.close()
     return 0
+
+
+def _want_hip_graph() -> bool:
+    v = str(FLAGS.hip_graph).strip().lower()
+    if v in ("auto", ""):
+        return FLAGS.mode == "async_ps"
+    if v in ("1", "true", "yes", "on"):
+        return True
+    if v in ("0", "false", "no", "off"):
+        return False
+    raise ValueError("--hip_graph must be true, false or auto (got %r)" % FLAGS.hip_graph)
 
 
 def main(unused_argv):
