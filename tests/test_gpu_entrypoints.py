@@ -82,6 +82,28 @@ def test_collective_trainer_checkpoint_resume_export_on_gpu(tmp_path):
     assert out["classes"].shape == (3, 1) and np.isfinite(out["scores"]).all()
 
 
+def test_ps_worker_on_gpu_via_tf_config(tmp_path):
+    """TF_CONFIG roles with the worker on the GPU: one ps task (CPU) + one worker whose device step is replayed
+    from a HIP graph (--hip_graph=auto), checkpoint written by the chief, ps stopped at the end."""
+    import socket
+
+    def port():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+    cluster = {"ps": ["localhost:%d" % port()], "worker": ["localhost:%d" % port()]}
+    common = ["train_dataset.py", "--synthetic", "--model=flower_cnn", "--image_size=64", "--batch_size=8",
+              "--train_steps=10", "--checkpoint_dir=%s/ckpt/" % tmp_path, "--summaries_dir=%s/events/" % tmp_path]
+    procs = []
+    for task, dev in (({"type": "ps", "index": 0}, "cpu"), ({"type": "worker", "index": 0}, "cuda")):
+        env = dict(os.environ, TF_CONFIG=json.dumps({"cluster": cluster, "task": task}))
+        procs.append(subprocess.Popen([sys.executable] + common + ["--device=" + dev], cwd=DIST, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert "finished training (worker 0" in outs[1]
+    assert int(bundle.read_bundle(bundle.latest_checkpoint(str(tmp_path / "ckpt")))["global_step"]) == 10
+
+
 @pytest.mark.gpu
 def test_model_server_on_gpu_matches_servable(tmp_path):
     """REST server over the HIP inference path: batched answers equal the servable called directly."""
