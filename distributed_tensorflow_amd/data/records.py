@@ -9,6 +9,12 @@ pinned buffers; the batch is uploaded with one copy and resized on the GPU to
 ``[B, 299, 299, 8]`` (bilinear, TensorFlow legacy coordinates, like
 ``tf.image.resize_images(method=0)``).
 
+On a GPU the upload and the resize of batch *k+1* are enqueued on a dedicated HIP stream while the
+training step of batch *k* runs on the compute stream (the device-side half of the reference's
+``prefetch(40)``): ``__next__`` hands out the batch prepared during the previous step, makes the compute
+stream wait for its event, and immediately starts the next one.  The host never waits for the compute
+stream; a pinned slot goes back to the loader threads once the copy stream has passed the batch's event.
+
 Differences from the reference, on purpose: examples (not whole batches) are
 shuffled, every rank reads a disjoint shard, pixels are converted to RGB and
 normalised to [-1, 1] (``legacy_bgr_unnormalised=True`` restores the reference's
@@ -39,6 +45,11 @@ class RecordInput:
         pin = self.device.type == "cuda"
         self._bufs = [torch.empty(cap, dtype=torch.uint8).pin_memory() if pin else torch.empty(cap, dtype=torch.uint8)
                       for _ in range(prefetch)]
+        # per-slot pinned staging for the small side tables (labels, image descriptors): every upload of a batch
+        # is an asynchronous copy from page-locked memory
+        self._lab_pin = [torch.empty(batch_size, dtype=torch.int32).pin_memory() for _ in range(prefetch)] if pin else []
+        self._desc_pin = [torch.empty(batch_size * C.sizeof(_ImageDesc), dtype=torch.uint8).pin_memory()
+                          for _ in range(prefetch)] if pin else []
         ptrs = (C.c_void_p * prefetch)(*[b.data_ptr() for b in self._bufs])
         self._h = self._L.dtfa_loader_open(path.encode(), rank, world, batch_size, threads, prefetch, ptrs, cap,
                                            seed, 1 if shuffle else 0, num_epochs, 1 if drop_remainder else 0)
@@ -46,17 +57,48 @@ class RecordInput:
             raise IOError("cannot open TFRecord file %s (missing, empty or corrupt)" % path)
         self.num_records = self._L.dtfa_loader_num_records(self._h)
         self.num_batches = self._L.dtfa_loader_num_batches(self._h)
+        # device-side prefetch: (x, labels, event, slot) or an exception, prepared on ``_stream``
+        self._stream = torch.cuda.Stream(device=self.device) if pin and prefetch >= 2 else None
+        self._pending = None
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         return self
 
     def __next__(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._stream is None:
+            return self._load()
+        if self._pending is None:
+            self._pending = self._prefetch()
+        item, self._pending = self._pending, None
+        if isinstance(item, BaseException):
+            raise item
+        x, labels, event, slot = item
+        event.synchronize()  # long done: it was recorded a whole training step ago
+        self._L.dtfa_loader_release(self._h, slot)
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(event)
+        # allocated on the copy stream, consumed (and later freed) on the compute stream
+        x.record_stream(main)
+        labels.record_stream(main)
+        self._pending = self._prefetch()
+        return x, labels
+
+    def _prefetch(self):
+        try:
+            with torch.cuda.stream(self._stream):
+                x, labels, slot = self._load(release=False)
+                return x, labels, self._stream.record_event(), slot
+        except BaseException as e:  # noqa: BLE001 -- StopIteration included: surfaces when this batch is asked for
+            return e
+
+    def _load(self, release: bool = True):
         b = hostlib.Batch()
         rc = self._L.dtfa_loader_next(self._h, C.byref(b))
         if rc == 0:
             raise StopIteration  # the reference surfaces this as OutOfRangeError -> should_stop()
         if rc < 0:
             raise IOError("record loader failed with code %d (bad record, or image larger than max_image_bytes)" % rc)
+        held = False
         try:
             n = b.count
             labels = torch.tensor([b.labels[i] for i in range(n)], dtype=torch.int32)
@@ -70,19 +112,31 @@ class RecordInput:
             host = self._bufs[b.slot][: int(b.bytes_used)]
             if self.device.type == "cuda":
                 dev = host.to(self.device, non_blocking=True)
-                dd = torch.from_numpy(np.frombuffer(descs, dtype=np.uint8).copy()).to(self.device, non_blocking=True)
+                nb = n * C.sizeof(_ImageDesc)
+                self._desc_pin[b.slot][:nb].copy_(torch.from_numpy(np.frombuffer(descs, dtype=np.uint8)))
+                dd = self._desc_pin[b.slot][:nb].to(self.device, non_blocking=True)
                 x = resize_on_device(dev, dd, n, size, "bilinear_legacy", bgr_to_rgb, norm)
+                self._lab_pin[b.slot][:n].copy_(labels)
+                lab = self._lab_pin[b.slot][:n].to(self.device, non_blocking=True)
+                if not release:
+                    held = True
+                    return x, lab, b.slot  # the caller releases the slot behind the stream's event
                 torch.cuda.current_stream().synchronize()  # the slot is reused after release
-                return x, labels.to(self.device)
+                return x, lab
             arr = host.numpy()
             images = [arr[b.offsets[i]: b.offsets[i] + b.heights[i] * b.widths[i] * b.channels[i]]
                       .reshape(b.heights[i], b.widths[i], b.channels[i]) for i in range(n)]
             x = preprocess_batch(images, size, "cpu", "bilinear_legacy", None, bgr_to_rgb, norm)
             return x, labels
         finally:
-            self._L.dtfa_loader_release(self._h, b.slot)
+            if not held:
+                self._L.dtfa_loader_release(self._h, b.slot)
 
     def close(self) -> None:
+        item, self._pending = getattr(self, "_pending", None), None
+        if self._h and isinstance(item, tuple):
+            item[2].synchronize()
+            self._L.dtfa_loader_release(self._h, item[3])
         if self._h:
             self._L.dtfa_loader_close(self._h)
             self._h = None

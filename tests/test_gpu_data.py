@@ -101,3 +101,30 @@ def test_record_input_on_device(tmp_path):
     assert x.is_cuda and x.dtype == torch.bfloat16 and y.is_cuda and y.tolist() == [0, 1, 2, 3]
     want = preprocess.resize_reference(imgs[1], (32, 32), "bilinear_legacy", bgr=True)
     np.testing.assert_allclose(x[1, :, :, :3].float().cpu().numpy(), want, atol=0.02)
+
+
+def test_record_input_prefetch_stream_matches_cpu_reader(tmp_path):
+    """Batches prepared one step ahead on the copy stream (several epochs, ragged last batch, busy compute stream)
+    equal the CPU reader's; the epoch end surfaces as StopIteration exactly after the last batch."""
+    path = str(tmp_path / "t.tfrecord")
+    rng = np.random.default_rng(1)
+    with tfrecord.TFRecordWriter(path) as w:
+        for i in range(37):
+            h, wd = int(rng.integers(20, 70)), int(rng.integers(20, 70))
+            img = rng.integers(0, 256, (h, wd, 3), dtype=np.uint8)
+            w.write(tfrecord.make_example({"image_raw": img.tobytes(), "label": i % 5, "height": h, "width": wd,
+                                           "channel": 3}))
+    kw = dict(image_size=24, num_epochs=3, shuffle=True, seed=7, max_image_bytes=1 << 16, prefetch=3)
+    cpu = list(RecordInput(path, 8, "cpu", **kw))
+    inp = RecordInput(path, 8, "cuda", **kw)
+    assert inp._stream is not None
+    busy = torch.randn(2048, 2048, device="cuda")
+    got = []
+    for x, y in inp:
+        busy = busy @ busy * 1e-3          # compute-stream work the copy stream overlaps with
+        got.append((x.float().cpu(), y.cpu()))
+    inp.close()
+    assert len(got) == len(cpu) == 14 and got[-1][0].shape[0] == 37 * 3 - 13 * 8
+    for (gx, gy), (cx, cy) in zip(got, cpu):
+        assert gy.tolist() == cy.tolist()
+        np.testing.assert_allclose(gx[..., :3].numpy(), cx[..., :3].float().numpy(), atol=0.02)
