@@ -83,6 +83,34 @@ def main():
         inp.close()
         print("raw-record path: %.0f images/s (batch %d, %d loader threads)" % (n / dt, batch, threads))
 
+        # the same reader feeding a training step (Inception-v3 head, the reference's model): with the upload +
+        # resize of the next batch on the copy stream, and with everything on the compute stream
+        from distributed_tensorflow_amd.models import build_model
+        from distributed_tensorflow_amd.parallel.engine import DataParallelEngine
+        from distributed_tensorflow_amd.train.session import TrainingSession
+
+        model = build_model("inception_v3_head", num_classes=5, device=dev)
+        eng = DataParallelEngine(model, mode="sync_dp", optimizer="adam", lr=1e-3)
+        sess = TrainingSession(model, eng, num_classes=5, hip_graph=True)
+        for overlap in (True, False):
+            inp = RecordInput(path, batch, dev, image_size=299, num_epochs=14, threads=threads, prefetch=4,
+                              drop_remainder=True)
+            if not overlap:
+                inp._stream = None
+            for _ in range(4):
+                sess.run_step(*next(inp))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 0
+            for x, y in inp:
+                sess.run_step(x, y)
+                n += x.shape[0]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            inp.close()
+            print("training from raw records, copy stream %s: %.0f images/s (%.2f ms/step)"
+                  % ("on " if overlap else "off", n / dt, dt / (n / batch) * 1e3))
+
 
 if __name__ == "__main__":
     main()
