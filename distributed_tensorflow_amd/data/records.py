@@ -22,6 +22,7 @@ BGR [0, 255] input).
 """
 from __future__ import annotations
 
+import concurrent.futures as cf
 import ctypes as C
 from typing import Iterator, Optional, Tuple
 
@@ -32,12 +33,21 @@ from ..io import hostlib
 from .preprocess import NORM_INCEPTION, NORM_NONE, _ImageDesc, preprocess_batch, resize_on_device
 
 
+# numpy mirror of preprocess._ImageDesc (same field order and C layout)
+_DESC_DTYPE = np.dtype([("offset", np.uint64), ("h", np.int32), ("w", np.int32), ("c", np.int32),
+                        ("crop_y0", np.float32), ("crop_x0", np.float32), ("crop_h", np.float32),
+                        ("crop_w", np.float32), ("flip", np.int32), ("pad", np.int32)], align=True)
+assert _DESC_DTYPE.itemsize == C.sizeof(_ImageDesc)
+
+
 class RecordInput:
     def __init__(self, path: str, batch_size: int, device, *, image_size: int = 299, num_epochs: int = 1,
                  rank: int = 0, world: int = 1, threads: int = 4, prefetch: int = 4, shuffle: bool = True,
                  seed: int = 0, drop_remainder: bool = False, legacy_bgr_unnormalised: bool = False,
                  max_image_bytes: int = 1 << 20):
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.batch_size, self.image_size = batch_size, image_size
         self.legacy = legacy_bgr_unnormalised
         self._L = hostlib.lib()
@@ -60,6 +70,9 @@ class RecordInput:
         # device-side prefetch: (x, labels, event, slot) or an exception, prepared on ``_stream``
         self._stream = torch.cuda.Stream(device=self.device) if pin and prefetch >= 2 else None
         self._pending = None
+        # the host half of preparing batch k+1 (waiting for the loader threads, side tables, enqueueing the
+        # upload) runs on a helper thread, so that the trainer enqueues step k without waiting for it
+        self._pool = cf.ThreadPoolExecutor(1, thread_name_prefix="dtfa-prefetch") if self._stream is not None else None
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         return self
@@ -68,8 +81,8 @@ class RecordInput:
         if self._stream is None:
             return self._load()
         if self._pending is None:
-            self._pending = self._prefetch()
-        item, self._pending = self._pending, None
+            self._pending = self._pool.submit(self._prefetch)
+        item, self._pending = self._pending.result(), None
         if isinstance(item, BaseException):
             raise item
         x, labels, event, slot = item
@@ -80,11 +93,12 @@ class RecordInput:
         # allocated on the copy stream, consumed (and later freed) on the compute stream
         x.record_stream(main)
         labels.record_stream(main)
-        self._pending = self._prefetch()
+        self._pending = self._pool.submit(self._prefetch)
         return x, labels
 
     def _prefetch(self):
         try:
+            torch.cuda.set_device(self.device)
             with torch.cuda.stream(self._stream):
                 x, labels, slot = self._load(release=False)
                 return x, labels, self._stream.record_event(), slot
@@ -101,11 +115,14 @@ class RecordInput:
         held = False
         try:
             n = b.count
-            labels = torch.tensor([b.labels[i] for i in range(n)], dtype=torch.int32)
-            descs = (_ImageDesc * n)()
-            for i in range(n):
-                h, w, c = b.heights[i], b.widths[i], b.channels[i]
-                descs[i] = _ImageDesc(b.offsets[i], h, w, c, 0.0, 0.0, float(h), float(w), 0, 0)
+            # the batch's side tables as arrays over the loader's memory (no per-image Python work)
+            lab_np = np.ctypeslib.as_array(b.labels, (n,))
+            hs, ws = np.ctypeslib.as_array(b.heights, (n,)), np.ctypeslib.as_array(b.widths, (n,))
+            descs = np.zeros(n, dtype=_DESC_DTYPE)
+            descs["offset"] = np.ctypeslib.as_array(b.offsets, (n,))
+            descs["h"], descs["w"], descs["c"] = hs, ws, np.ctypeslib.as_array(b.channels, (n,))
+            descs["crop_h"], descs["crop_w"] = hs, ws
+            labels = torch.from_numpy(lab_np.astype(np.int32))
             norm = NORM_NONE if self.legacy else NORM_INCEPTION
             bgr_to_rgb = not self.legacy
             size = (self.image_size, self.image_size)
@@ -113,7 +130,7 @@ class RecordInput:
             if self.device.type == "cuda":
                 dev = host.to(self.device, non_blocking=True)
                 nb = n * C.sizeof(_ImageDesc)
-                self._desc_pin[b.slot][:nb].copy_(torch.from_numpy(np.frombuffer(descs, dtype=np.uint8)))
+                self._desc_pin[b.slot][:nb].copy_(torch.from_numpy(descs.view(np.uint8)))
                 dd = self._desc_pin[b.slot][:nb].to(self.device, non_blocking=True)
                 x = resize_on_device(dev, dd, n, size, "bilinear_legacy", bgr_to_rgb, norm)
                 self._lab_pin[b.slot][:n].copy_(labels)
@@ -133,7 +150,11 @@ class RecordInput:
                 self._L.dtfa_loader_release(self._h, b.slot)
 
     def close(self) -> None:
-        item, self._pending = getattr(self, "_pending", None), None
+        fut, self._pending = getattr(self, "_pending", None), None
+        item = fut.result() if fut is not None else None
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         if self._h and isinstance(item, tuple):
             item[2].synchronize()
             self._L.dtfa_loader_release(self._h, item[3])

@@ -47,10 +47,10 @@ class StepGraph:
         eng = self.engine
         torch.cuda.synchronize()
         eng.prepare_step()
-        # With collectives in the step, RCCL's watchdog thread keeps polling events of earlier work while
-        # the capture runs; "thread_local" keeps those calls from invalidating the capture.
-        mode = "thread_local" if getattr(eng, "collective", False) else "global"
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):
+        # Other threads keep issuing HIP calls while the capture runs -- RCCL's watchdog polls events of earlier
+        # work, the input pipeline's helper thread uploads the next batch on its copy stream -- and
+        # "thread_local" keeps those calls from invalidating the capture.
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             eng.begin_step()
             out = loss_fn(self.images, self.labels)
             total = out[0]
