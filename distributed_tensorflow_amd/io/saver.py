@@ -123,6 +123,11 @@ class Saver:
         self.model, self.engine = model, engine
         self.max_to_keep, self.basename, self.power_scope = max_to_keep, basename, power_scope
         self.specs = model_variables(model)
+        # TensorFlow-layout copies of frozen parameters (the Inception trunk: 22 M of the flower model's 24 M
+        # values), reused from save to save until the parameter is written or replaced
+        self._frozen: Dict[str, tuple] = {}
+        self._writer = None       # background file writer (save(background=True))
+        self._write_future = None
 
     # ------------------------------------------------------------------ collect
     def _segment_views(self):
@@ -135,7 +140,14 @@ class Saver:
                 m[id(seg.param)] = (g.name, seg.offset, seg.numel)
         return m
 
-    def variables(self, include_slots: bool = True) -> Dict[str, np.ndarray]:
+    def variables(self, include_slots: bool = True, detach_host: bool = False) -> Dict[str, np.ndarray]:
+        """TensorFlow-named arrays of every variable.  ``detach_host``: arrays never alias live host tensors
+        (what a background writer needs while training keeps updating them)."""
+
+        def host(t):
+            a = t.cpu().numpy()
+            return a.copy() if (detach_host and t.device.type == "cpu") else a
+
         segs = self._segment_views()
         master = self.engine.full_master() if self.engine is not None else {}
         slots = self.engine.full_slots() if (self.engine is not None and include_slots) else {}
@@ -148,14 +160,26 @@ class Saver:
                 val = master[gname][off:off + n].view(t.shape)
             else:
                 val = t.detach()
-            out[spec.name] = spec.to_tf(val.float()).cpu().numpy()
+            # a parameter nothing trains changes only through copy_ / .data assignment (restore, casts), which
+            # move its version counter or its storage; running statistics are written by kernels behind
+            # torch's back and are never cached
+            frozen = loc is None and isinstance(t, nn.Parameter) and not t.requires_grad
+            key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype) if frozen else None
+            hit = self._frozen.get(spec.name) if frozen else None
+            if hit is not None and hit[0] == key:
+                out[spec.name] = hit[1]
+            else:
+                out[spec.name] = host(spec.to_tf(val.float()))
+                if frozen:
+                    out[spec.name].setflags(write=False)
+                    self._frozen[spec.name] = (key, out[spec.name])
             if loc is not None:
                 for key, flat in slots.items():
                     slot, g2 = key.rsplit("/", 1)
                     if g2 != gname:
                         continue
                     sv = flat[off:off + n].view(t.shape)
-                    out[spec.name + "/" + SLOT_SUFFIX.get(slot, slot)] = spec.to_tf(sv.float()).cpu().numpy()
+                    out[spec.name + "/" + SLOT_SUFFIX.get(slot, slot)] = host(spec.to_tf(sv.float()))
         return out
 
     def gather_only(self) -> None:
@@ -165,10 +189,21 @@ class Saver:
             self.engine.full_slots()
 
     # ------------------------------------------------------------------ save
+    def wait(self) -> None:
+        """Block until a background save has written its files (raises what the writer raised)."""
+        fut, self._write_future = self._write_future, None
+        if fut is not None:
+            fut.result()
+
     def save(self, checkpoint_dir: str, global_step: int, write_state: bool = True,
-             extra: Optional[Dict[str, np.ndarray]] = None, write_meta: bool = True) -> str:
+             extra: Optional[Dict[str, np.ndarray]] = None, write_meta: bool = True, background: bool = False) -> str:
+        """Write ``<checkpoint_dir>/<basename>-<global_step>.{index,data-00000-of-00001,meta}`` and update the
+        ``checkpoint`` state file.  With ``background`` the variables are snapshotted now (host copies in
+        TensorFlow layout) and the files are written by a helper thread while training continues; the next
+        save, :meth:`wait` or a restore joins it first, so files appear in step order."""
+        self.wait()
         os.makedirs(checkpoint_dir, exist_ok=True)
-        tensors = self.variables()
+        tensors = self.variables(detach_host=background)
         tensors["global_step"] = np.array(int(global_step), dtype=np.int64)
         opt = getattr(self.engine, "optimizer", None)
         if opt is not None and getattr(opt, "beta1_power", None) is not None:
@@ -178,23 +213,35 @@ class Saver:
             tensors.update(extra)
         base = "%s-%d" % (self.basename, int(global_step))
         prefix = os.path.join(checkpoint_dir, base)
-        bundle.write_bundle(prefix, tensors)
-        if write_meta:
-            from .metagraph import encode_meta_graph
 
-            trainable = {v.name: v.trainable for v in self.specs}
-            names = [(n, trainable.get(n, False)) for n in sorted(tensors, key=lambda k: k.encode())]
-            tmp = prefix + ".meta.tmp%d" % os.getpid()
-            with open(tmp, "wb") as f:
-                f.write(encode_meta_graph(names, self.max_to_keep))
-            os.replace(tmp, prefix + ".meta")
-        if write_state:
-            bundle.update_checkpoint_state(checkpoint_dir, base, self.max_to_keep)
+        def write():
+            bundle.write_bundle(prefix, tensors)
+            if write_meta:
+                from .metagraph import encode_meta_graph
+
+                trainable = {v.name: v.trainable for v in self.specs}
+                names = [(n, trainable.get(n, False)) for n in sorted(tensors, key=lambda k: k.encode())]
+                tmp = prefix + ".meta.tmp%d" % os.getpid()
+                with open(tmp, "wb") as f:
+                    f.write(encode_meta_graph(names, self.max_to_keep))
+                os.replace(tmp, prefix + ".meta")
+            if write_state:
+                bundle.update_checkpoint_state(checkpoint_dir, base, self.max_to_keep)
+
+        if background:
+            if self._writer is None:
+                import concurrent.futures as cf
+
+                self._writer = cf.ThreadPoolExecutor(1, thread_name_prefix="dtfa-ckpt")
+            self._write_future = self._writer.submit(write)
+        else:
+            write()
         return prefix
 
     # ------------------------------------------------------------------ restore
     def restore(self, prefix: str, strict: bool = False, restore_slots: bool = True) -> int:
         """Load by variable name; returns the checkpoint's global step (0 when absent)."""
+        self.wait()
         data = bundle.read_bundle(prefix)
         segs = self._segment_views()
         missing = []
@@ -244,6 +291,7 @@ class Saver:
         return step
 
     def restore_latest(self, checkpoint_dir: str, **kw) -> Optional[int]:
+        self.wait()
         prefix = bundle.latest_checkpoint(checkpoint_dir)
         if prefix is None:
             return None

@@ -63,6 +63,8 @@ class ConvBnAct(nn.Module):
 
     def forward_pool(self, x, kernel=(3, 3), stride=(2, 2), padding="VALID"):
         """This layer followed by a max-pool, fused on the device (the un-pooled activation is not stored)."""
+        if self.training:
+            self._coeff_cache = None  # the kernels update the running statistics in place, behind torch's versions
         return F.conv_bn_act_pool(x, self.weight, self.gamma, self.beta, self.running_mean, self.running_var,
                                   stride=self.stride, padding=self.padding, eps=self.eps, momentum=self.momentum,
                                   relu=self.relu, training=self.training, pool_kernel=_pair(kernel),
@@ -82,7 +84,9 @@ class ConvBnAct(nn.Module):
 
     def forward(self, x, residual=None, links=None, out=None):
         coeffs = None
-        if not self.training and x.is_cuda and not torch.is_grad_enabled():
+        if self.training:
+            self._coeff_cache = None  # the kernels update the running statistics in place, behind torch's versions
+        elif x.is_cuda and not torch.is_grad_enabled():
             coeffs = self._eval_coeffs()
         return F.conv_bn_act(x, self.weight, self.gamma, self.beta, self.running_mean, self.running_var,
                              stride=self.stride, padding=self.padding, eps=self.eps, momentum=self.momentum,

@@ -78,6 +78,11 @@ def main(argv):
     model_name = FLAGS.model
     if model_name == "auto":
         model_name = "inception_v3_head" if device.type == "cuda" else "flower_cnn"
+    # one seed for every generator the run draws from (the reference's reset_graph(seed) seeds TensorFlow and
+    # numpy, recognition_flower/single/flower_train.py:35-38; batches are drawn with Python's random.sample)
+    import random
+
+    random.seed(FLAGS.seed)
     torch.manual_seed(FLAGS.seed)
     np_rng = np.random.default_rng(FLAGS.seed)
 

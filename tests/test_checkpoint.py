@@ -254,3 +254,36 @@ def test_trunk_bn_moving_keeps_trunk_normalisation_frozen():
     assert {v.name for v in model_variables(m)} == ref_names
     with pytest.raises(ValueError):
         build_model("inception_v3_head", trunk_bn="frozen")
+
+
+def test_background_save_snapshots_now_and_caches_frozen_variables(tmp_path):
+    """save(background=True): the files hold the values at the time of the call although training goes on while the
+    helper thread writes; frozen parameters are converted once and re-converted after a restore."""
+    model = build_model("inception_v3_head")
+    eng = DataParallelEngine(model, mode="sync_dp", optimizer="adam", lr=1e-2)
+    saver = Saver(model, eng)
+    before = {g.name: g.master.clone() for g in eng.flat.groups}
+    saver.save(str(tmp_path), 1, background=True)
+    for g in eng.flat.groups:           # "training" continues: the live master changes under the writer
+        g.master.add_(1.0)
+    saver.wait()
+    data = bundle.read_bundle(bundle.latest_checkpoint(str(tmp_path)))
+    k = data["fc_trainable/flower_logits/kernel"]
+    assert k.shape == (1024, 5)
+    want = model.head.flower_logits.weight.detach()[:5].t() - 1.0   # parameters view the (moved) master
+    np.testing.assert_allclose(k, want.numpy(), rtol=0, atol=1e-6)   # (x + 1) - 1 rounds; the moved values are 1 off
+    assert int(data["global_step"]) == 1
+    # frozen trunk: same array object on the next save, a fresh one after the parameter is rewritten
+    name = "InceptionV3/Conv2d_1a_3x3/weights"
+    first = saver.variables()[name]
+    assert saver.variables()[name] is first and not first.flags.writeable
+    with torch.no_grad():
+        model.trunk.Conv2d_1a_3x3.weight.mul_(2.0)
+    second = saver.variables()[name]
+    assert second is not first and np.allclose(second, first * 2)
+    # saves queue up in step order and restore joins the writer
+    saver.save(str(tmp_path), 2, background=True)
+    saver.save(str(tmp_path), 3, background=True)
+    assert saver.restore_latest(str(tmp_path)) == 3
+    assert bundle.read_checkpoint_state(str(tmp_path))[0] == "model.ckpt-3"
+    del before
