@@ -163,7 +163,8 @@ class Saver:
             # a parameter nothing trains changes only through copy_ / .data assignment (restore, casts), which
             # move its version counter or its storage; running statistics are written by kernels behind
             # torch's back and are never cached
-            frozen = loc is None and isinstance(t, nn.Parameter) and not t.requires_grad
+            frozen = (loc is None and isinstance(t, nn.Parameter) and not t.requires_grad
+                      and not getattr(self, "_frozen_disabled", False))  # (switch for tools/bench_ckpt.py)
             key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype) if frozen else None
             hit = self._frozen.get(spec.name) if frozen else None
             if hit is not None and hit[0] == key:
