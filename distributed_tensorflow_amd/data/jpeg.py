@@ -15,6 +15,7 @@ with libjpeg to within IDCT rounding.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import io
 from concurrent.futures import ThreadPoolExecutor
 from typing import List, Optional, Sequence, Tuple
@@ -91,12 +92,27 @@ def reconstruct_reference(info, coefs: np.ndarray) -> np.ndarray:
 
 
 _pool: Optional[ThreadPoolExecutor] = None
+_pool_size = 0
+
+
+def default_threads() -> int:
+    """Host threads for the entropy decode: DTFA_JPEG_THREADS, else the process's thread budget
+    (OMP_NUM_THREADS where the launcher sets one), else the CPUs this process may run on; at most 32."""
+    for var in ("DTFA_JPEG_THREADS", "OMP_NUM_THREADS"):
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) > 0:
+            return min(int(v), 32)
+    try:
+        return max(1, min(len(os.sched_getaffinity(0)), 32))
+    except AttributeError:
+        return 8
 
 
 def _executor(threads: int) -> ThreadPoolExecutor:
-    global _pool
-    if _pool is None:
+    global _pool, _pool_size
+    if _pool is None or _pool_size < threads:
         _pool = ThreadPoolExecutor(max_workers=threads, thread_name_prefix="dtfa-jpeg")
+        _pool_size = threads
     return _pool
 
 
@@ -121,7 +137,7 @@ def _coef_staging(device: torch.device, n_int16: int) -> torch.Tensor:
     return buf, ring, k
 
 
-def decode_batch_to_device(jpegs: Sequence[bytes], device, threads: int = 8):
+def decode_batch_to_device(jpegs: Sequence[bytes], device, threads: Optional[int] = None):
     """Decode a batch of JPEG byte strings.
 
     Returns ``(packed uint8 device buffer of RGB HWC images, shapes, offsets)``;
@@ -135,6 +151,7 @@ def decode_batch_to_device(jpegs: Sequence[bytes], device, threads: int = 8):
     from ..ops import hipk
 
     device = torch.device(device)
+    threads = threads or default_threads()
     Lh = hostlib.lib()
     n = len(jpegs)
     infos: List[Optional[hostlib.JpegInfo]] = []

@@ -52,6 +52,7 @@ flags.DEFINE_string("trunk_bn", "batch", "Inception trunk batch-norm while train
 flags.DEFINE_string("device", "auto", "cuda | cpu | auto")
 flags.DEFINE_integer("max_steps", 0, "Stop after this many steps (0 = n_epochs * iterations per epoch).")
 flags.DEFINE_integer("seed", 42, "Random seed.")
+flags.DEFINE_boolean("prefetch", True, "GPU: prepare the next batch on a helper thread and a copy stream during the step.")
 flags.DEFINE_string("checkpoint_dir", "", "Also write a training checkpoint here at the end (optional).")
 flags.DEFINE_string("profile_dir", "", "Write a torch.profiler Chrome trace of a few steps here (empty = off).")
 flags.DEFINE_boolean("hip_graph", True, "replay the training step from a HIP graph (GPU only; steps of a different batch size run eagerly)")
@@ -124,19 +125,28 @@ def main(argv):
         Xp[..., :3] = X
         return torch.from_numpy(Xp), torch.from_numpy(y)
 
+    # on a GPU the next training batch is read, decoded and augmented on a helper thread and a copy stream while
+    # the current step runs
+    prefetcher = None
+    if device.type == "cuda" and FLAGS.prefetch:
+        from distributed_tensorflow_amd.data.prefetch import DevicePrefetcher
+
+        prefetcher = DevicePrefetcher(lambda: next_batch(train, batch_size), device)
     t0 = time.time()
     done = False
     with sess:
         for epoch in range(FLAGS.n_epochs):
             print("Epoch", epoch, end="\n")
             for _ in range(n_iterations_per_epoch):
-                X, y = next_batch(train, batch_size)
+                X, y = prefetcher.next() if prefetcher is not None else next_batch(train, batch_size)
                 sess.run_step(X, y)
                 if FLAGS.max_steps and sess.global_step - global_step >= FLAGS.max_steps:
                     done = True
                     break
             if done:
                 break
+        if prefetcher is not None:
+            prefetcher.close()
         if test:
             bs = min(len(test), batch_size)
             X, y = next_batch(test, bs)
