@@ -42,8 +42,50 @@ def synthetic_jpegs(n, hw=(320, 400), seed=0):
     return out
 
 
+def run_grpc_clients(port, threads_n, seconds):
+    """Client process: THREADS channels sending single-image Predict requests for SECONDS."""
+    import grpc
+
+    from distributed_tensorflow_amd.serving import tfs_proto as P
+
+    jpegs = synthetic_jpegs(16)
+    reqs = []
+    for j in jpegs:
+        r = P.PredictRequest()
+        r.model_spec.name, r.model_spec.signature_name = "flowers", "predict_images"
+        r.inputs["images"].CopyFrom(P.string_tensor([j]))
+        reqs.append(r.SerializeToString())
+    counts, lat = [0] * threads_n, [0.0] * threads_n
+    t_start = time.perf_counter()
+    stop = t_start + seconds
+
+    def client(i):
+        ch = grpc.insecure_channel("127.0.0.1:%d" % port, options=[("grpc.max_send_message_length", 64 << 20)])
+        call = ch.unary_unary("/tensorflow.serving.PredictionService/Predict", request_serializer=lambda b: b,
+                              response_deserializer=P.PredictResponse.FromString)
+        k = i
+        while time.perf_counter() < stop:
+            t0 = time.perf_counter()
+            call(reqs[k % len(reqs)], timeout=60)
+            lat[i] += time.perf_counter() - t0
+            counts[i] += 1
+            k += 1
+        ch.close()
+
+    threads = [threading.Thread(target=client, args=(i,)) for i in range(threads_n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    print(json.dumps({"requests": sum(counts), "latency_sum": sum(lat), "seconds": time.perf_counter() - t_start}))
+    return 0
+
+
 def run_clients(spec):
     """Client process: THREADS keep-alive connections posting single-image predict requests for SECONDS."""
+    if spec.startswith("grpc:"):
+        port, threads_n, seconds = spec[5:].split(",")
+        return run_grpc_clients(int(port), int(threads_n), float(seconds))
     port, threads_n, seconds = spec.split(",")
     port, threads_n, seconds = int(port), int(threads_n), float(seconds)
     jpegs = synthetic_jpegs(16)
@@ -124,21 +166,30 @@ def main():
             warm.getresponse().read()
     procs_n = max(1, min(args.client_procs, args.clients))
     per = [args.clients // procs_n + (1 if i < args.clients % procs_n else 0) for i in range(procs_n)]
-    b0 = server.batcher.stats()
-    t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--client_of",
-                               "%d,%d,%f" % (server.port, n, args.seconds)], stdout=subprocess.PIPE, text=True)
-             for n in per]
-    results = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
-    dt = time.perf_counter() - t0
-    total = sum(r["requests"] for r in results)
-    lat_sum = sum(r["latency_sum"] for r in results)
-    span = max(r["seconds"] for r in results)
-    st = server.batcher.stats()
-    batches, items = st["batches"] - b0["batches"], st["items"] - b0["items"]
-    print("REST server, %d clients x 1 image: %.1f requests/s, mean latency %.2f ms, mean batch %.1f, "
-          "device busy %.0f%%" % (args.clients, total / span, lat_sum / max(total, 1) * 1e3, items / max(batches, 1),
-                                  100 * (st["busy_seconds"] - b0["busy_seconds"]) / dt), flush=True)
+    from distributed_tensorflow_amd.serving import GrpcModelServer
+
+    grpc_server = GrpcModelServer(manager, server.batcher, port=0, max_workers=max(16, args.clients)).start()
+
+    def timed(label, spec_of):
+        b0 = server.batcher.stats()
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--client_of", spec_of(n)],
+                                  stdout=subprocess.PIPE, text=True) for n in per]
+        results = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+        dt = time.perf_counter() - t0
+        total = sum(r["requests"] for r in results)
+        lat_sum = sum(r["latency_sum"] for r in results)
+        span = max(r["seconds"] for r in results)
+        st = server.batcher.stats()
+        batches, items = st["batches"] - b0["batches"], st["items"] - b0["items"]
+        print("%s, %d clients x 1 image: %.1f requests/s, mean latency %.2f ms, mean batch %.1f, "
+              "device busy %.0f%%" % (label, args.clients, total / span, lat_sum / max(total, 1) * 1e3,
+                                      items / max(batches, 1), 100 * (st["busy_seconds"] - b0["busy_seconds"]) / dt),
+              flush=True)
+
+    timed("REST server", lambda n: "%d,%d,%f" % (server.port, n, args.seconds))
+    timed("gRPC server (PredictionService/Predict)", lambda n: "grpc:%d,%d,%f" % (grpc_server.port, n, args.seconds))
+    grpc_server.stop()
     server.stop()
 
 
