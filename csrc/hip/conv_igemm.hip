@@ -32,7 +32,8 @@ struct ConvArgs {
   const bf16* w;
   bf16* y;
   const float* bias;   // [Cout] or null
-  const bf16* addend;  // optional tensor of the output's shape, added in the epilogue (residual gradient)
+  const bf16* addend;  // optional tensor of the output's shape, added in the epilogue (residual gradient; with the
+                       // bias / ReLU epilogue: the residual of a block, added before the ReLU)
   const unsigned char* addend_mask;  // optional: one bit per element of addend, only set elements are added
   float* stats;        // [mtiles][2][Cout] partial (sum, sumsq) or null
   const bf16* zero;    // >= 16 bytes of zeros, 16-byte aligned
@@ -120,6 +121,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
   constexpr int NP = WM / RPP;        // passes
   const bool chunk_live = (lane % CPR) < CHUNKS;
   const int chunk_co = n0 + wc * WN + (lane % CPR) * 8;
+  size_t last_pixel = 0;  // physical output pixel of the latest out_offset() call
   auto out_offset = [&](int pass, bool& ok) -> size_t {
     const int m = m0 + wr * WM + pass * RPP + lane / CPR;
     ok = m < p.M && chunk_co < p.Cout && chunk_live;
@@ -135,6 +137,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
         opixel = ((size_t)b * p.OH + (oy * p.osy + p.oy0)) * p.OW + (ox * p.osx + p.ox0);
       }
     }
+    last_pixel = opixel;
     return opixel * ldo + chunk_co;
   };
   char* ep = lds_tiles + wid * (WM * EP_PITCH);
@@ -147,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
     float bias = 0.f, osc = 1.f;
     if (EPI == 2 && p.bias != nullptr && co < p.Cout) bias = p.bias[co];
     if (EPI == 2 && p.oscale != nullptr && co < p.Cout) osc = p.oscale[co];
-    const bool relu = EPI == 2 && p.relu != 0;
+    const bool relu = EPI == 2 && p.relu != 0 && p.addend == nullptr;  // with a residual the ReLU follows the add
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -211,7 +214,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
       const size_t off = out_offset(pass, ok);
       if (ok) {
         const int r = pass * RPP + lane / CPR;
-        out_store((bf16x8*)(p.y + off), *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16));
+        bf16x8 v = *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16);
+        if (EPI == 2 && p.addend != nullptr) {
+          // inference residual block: act(conv * scale + shift + residual); the residual is dense ([.., Cout])
+          const bf16x8 res = epi_load((const bf16x8*)(p.addend + last_pixel * p.Cout + chunk_co));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j] + (float)res[j];
+            v[j] = (bf16)(p.relu ? fmaxf(f, 0.f) : f);
+          }
+        }
+        out_store((bf16x8*)(p.y + off), v);
       }
     }
   } else {
@@ -662,7 +675,10 @@ extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int ns
   if (a->K != a->T * a->Cin || a->K >= (1 << 16)) return -2;
   if ((long long)a->IH * a->IW >= (1ll << 24) || (long long)a->IH * a->IW * a->Cin >= (1ll << 32)) return -2;
   if (a->stats != nullptr && a->bias != nullptr) return -4;
-  if (a->addend != nullptr && (a->bias != nullptr || a->relu || (a->stats != nullptr && a->bn_y == nullptr))) return -4;
+  // a residual in the bias / ReLU (forward) epilogue: no bitmask, no statistics
+  const bool fwd_residual = a->addend != nullptr && (a->bias != nullptr || a->relu || a->oscale != nullptr);
+  if (fwd_residual && (a->addend_mask != nullptr || a->stats != nullptr || a->bn_y != nullptr)) return -4;
+  if (a->addend != nullptr && !fwd_residual && a->stats != nullptr && a->bn_y == nullptr) return -4;
   if (a->bn_y != nullptr) {
     if (a->stats == nullptr || a->bn_mean == nullptr || a->bn_invstd == nullptr || a->bias != nullptr || a->relu) return -5;
     if (a->bn_relu == 2 && (a->bn_scale == nullptr || a->bn_shift == nullptr)) return -5;
@@ -670,7 +686,8 @@ extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int ns
     if (a->bn_relu != 0 && a->bn_relu != 2 && a->bn_relu != 3) return -5;
   }
   if (a->ldo < a->Cout || a->ldo % 8 != 0) return -6;
-  if ((a->oscale != nullptr || a->ldo != a->Cout) && (a->stats != nullptr || a->addend != nullptr || a->bn_y != nullptr)) return -6;
+  if ((a->oscale != nullptr || a->ldo != a->Cout) && (a->stats != nullptr || a->bn_y != nullptr)) return -6;
+  if (a->ldo != a->Cout && a->addend != nullptr && !fwd_residual) return -6;
   if (a->M <= 0) return 0;
   // bm == 256: two wave groups of 128 rows sharing one weight tile
   if (bm == 256 && bn == 128 && bk == 32 && nst == 3) return launch_conv_epi<128, 128, 32, 3, 2>(*a, stream);

@@ -268,11 +268,12 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
 
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[torch.Tensor] = None,
              relu: bool = False, want_stats: bool = False, scale: Optional[torch.Tensor] = None,
-             out: Optional[torch.Tensor] = None):
+             out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None):
     """x [B,IH,IW,Cin] bf16, w [Cout,KH,KW,Cin] bf16 -> (y [B,OH,OW,Cout] bf16, stats partials or None).
 
     ``scale`` / ``bias`` ([Cout] fp32) turn the epilogue into ``act(conv * scale + bias)`` -- a convolution with
-    its inference-mode batch-norm folded in.  ``out`` is a channel slice ``buf[..., c0:c0+Cout]`` of a contiguous
+    its inference-mode batch-norm folded in; ``residual`` ([B,OH,OW,Cout] bf16, with ``bias`` or ``scale``) is added
+    before the activation (the tail of a residual block).  ``out`` is a channel slice ``buf[..., c0:c0+Cout]`` of a contiguous
     NHWC tensor (``c0`` and the buffer's channel count multiples of 8) that receives the rows directly."""
     hipk.require(x, torch.bfloat16, "x")
     hipk.require(w, torch.bfloat16, "w")
@@ -291,6 +292,10 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
         hipk.require(scale, torch.float32, "scale")
         if scale.numel() != plan.cout or want_stats:
             raise ValueError("scale needs Cout entries and excludes batch-norm statistics")
+    if residual is not None:
+        hipk.require(residual, torch.bfloat16, "residual")
+        if tuple(residual.shape) != (B, plan.oh, plan.ow, plan.cout) or want_stats or (bias is None and scale is None):
+            raise ValueError("residual needs the output's shape and the bias / scale epilogue")
     if B * plan.oh * plan.ow >= 1 << 31:
         raise ValueError("too many output pixels for 32-bit row indices")
     ldo = 0
@@ -305,7 +310,7 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
             raise ValueError("out must be a 16-byte aligned channel slice of a contiguous NHWC bf16 tensor")
     part = _launch_igemm(x, w, y, plan.fwd_taps, plan.T, plan.ih, plan.iw, plan.cin, plan.oh, plan.ow, plan.cout,
                          plan.oh, plan.ow, 1, 1, 0, 0, plan.sy, plan.sx, B, plan.cin_magic, bias, relu, want_stats,
-                         zero_taps=plan.is_pointwise, oscale=scale, ldo=ldo)
+                         addend=residual, zero_taps=plan.is_pointwise, oscale=scale, ldo=ldo)
     return y, part
 
 

@@ -448,9 +448,9 @@ def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, e
     """``act(bn(conv(x, weight)) + residual)``; batch statistics when ``training``.
     ``links`` (:class:`Links`) wires the layer's backward pass to its neighbours in a residual block.
 
-    Inference (``training`` false, nothing requiring grad, no residual) on the device is ONE kernel: the
-    normalisation is folded into the convolution's epilogue as a per-channel multiply-add on the fp32
-    accumulators.  ``eval_coeffs`` = cached ``(scale, shift)`` of the running statistics (computed if absent).
+    Inference (``training`` false, nothing requiring grad) on the device is ONE kernel: the normalisation is
+    folded into the convolution's epilogue as a per-channel multiply-add on the fp32 accumulators, a residual
+    is added there before the activation.  ``eval_coeffs`` = cached ``(scale, shift)`` of the running statistics (computed if absent).
 
     ``out`` (device path, nothing requiring grad) is a channel slice of a wider NHWC tensor that
     receives the result directly -- the way parallel branches are concatenated without a copy."""
@@ -461,9 +461,9 @@ def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, e
         if not _use_hip(x) or _needs_grad(x, weight, gamma, beta, residual):
             raise ValueError("out= is a forward-only device path")
         plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], weight.shape[0], kh, kw, sy, sx, pads, x.device)
-        if not training and residual is None:
+        if not training:
             scale, shift = eval_coeffs or K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
-            return cv.conv_fwd(x, weight, plan, bias=shift, relu=relu, scale=scale, out=out)[0]
+            return cv.conv_fwd(x, weight, plan, bias=shift, relu=relu, scale=scale, out=out, residual=residual)[0]
         y, part = cv.conv_fwd(x, weight, plan, want_stats=training)
         if training:
             _, _, scale, shift = K.bn_finalize(part, y.numel() // plan.cout, eps, gamma, beta, run_mean, run_var,
@@ -481,9 +481,10 @@ def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, e
             z = z + residual
         return torch.relu(z) if relu else z
     plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], weight.shape[0], kh, kw, sy, sx, pads, x.device)
-    if not training and residual is None and not _needs_grad(x, weight, gamma, beta):
+    if not training and not _needs_grad(x, weight, gamma, beta, residual):
         scale, shift = eval_coeffs or K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
-        return cv.conv_fwd(x, weight, plan, bias=shift, relu=relu, scale=scale)[0]
+        res = residual.contiguous() if residual is not None else None
+        return cv.conv_fwd(x, weight, plan, bias=shift, relu=relu, scale=scale, residual=res)[0]
     links = links if links is not None else _NO_LINKS
     if links.input_grad is not None and (plan.dgrad_needs_zero or not x.requires_grad):
         raise ValueError("input_grad needs an input that requires grad and a dgrad that writes every pixel")

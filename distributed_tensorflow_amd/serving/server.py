@@ -104,8 +104,12 @@ class ModelServer:
                 code, body = server.handle_post(self.path, raw)
                 self._send(code, body)
 
-        self.httpd = ThreadingHTTPServer((host, port), Handler)
-        self.httpd.daemon_threads = True
+        class Server(ThreadingHTTPServer):
+            # socketserver listens with a backlog of 5: a burst of a few dozen connecting clients gets resets
+            request_queue_size = 1024
+            daemon_threads = True
+
+        self.httpd = Server((host, port), Handler)
         self.port = self.httpd.server_address[1]
         self._thread: Optional[threading.Thread] = None
 

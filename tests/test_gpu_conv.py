@@ -91,6 +91,13 @@ def test_conv_folded_batchnorm_into_channel_slice(case):
     assert (buf[..., :16] == 7).all() and (buf[..., 16 + Cout:] == 7).all()
     with pytest.raises(ValueError):
         cv.conv_fwd(xb.cuda(), wb.cuda(), plan, bias=shift.cuda(), out=buf[..., 4:4 + Cout])  # not 16-byte aligned
+    # tail of a residual block: relu(conv * scale + shift + residual), with and without the activation
+    res = torch.randn(want.shape, generator=g).bfloat16()
+    pre = ref.conv2d(xb.float(), wb.float(), (sy, sx), pads) * scale + shift + res.float()
+    for relu in (True, False):
+        z, _ = cv.conv_fwd(xb.cuda(), wb.cuda(), plan, bias=shift.cuda(), relu=relu, scale=scale.cuda(),
+                           residual=res.cuda())
+        torch.testing.assert_close(z.float().cpu(), torch.relu(pre) if relu else pre, rtol=2e-2, atol=3e-2)
 
 
 @pytest.mark.parametrize("case", CASES)
