@@ -308,13 +308,14 @@ class TrainingSession:
             self._eager_steps += 1
         total, xent, logits, top1, score, correct = out
         self.global_step += 1
-        # .item() synchronises with the device, so step_time covers the whole step
-        loss_v = float(total.detach().float().item())
-        acc = float(correct.float().mean().item())
+        # one device-to-host transfer for the three scalars; it synchronises with the device, so step_time covers
+        # the whole step
+        loss_v, acc, xent_v = torch.stack([total.detach().float().reshape(()), correct.float().mean(),
+                                           xent.detach().float().reshape(())]).tolist()
         dt = time.perf_counter() - t0
         r = StepResult(self.global_step, loss_v, acc, lr, int(labels.shape[0]), dt,
                        logits.detach()[:, :self.num_classes] if self.keep_logits else None,
-                       {"xent": float(xent.detach().float().item())})
+                       {"xent": xent_v})
         for h in self.hooks:
             h.after_step(self, r)
         return r
