@@ -7,12 +7,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributed_tensorflow_amd.ops import conv as cv  # noqa: E402
-from tools.bench_conv import INCEPTION, RESNET, normalise, timeit  # noqa: E402
+from tools.bench_conv import FLOWER, INCEPTION, RESNET, normalise, timeit  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 which = sys.argv[2] if len(sys.argv) > 2 else "fwd"
 FWD = [(bm, bn, bk, nst) for (bm, bn) in ((128, 192), (128, 128), (128, 64), (64, 64)) for bk in (32, 64) for nst in (2, 3)]
-TABLE = INCEPTION if (len(sys.argv) > 3 and sys.argv[3] == "inception") else RESNET
+FWD += [(256, 128, 32, 3), (256, 256, 64, 2)]
+TABLE = {"inception": INCEPTION, "flower": FLOWER}.get(sys.argv[3] if len(sys.argv) > 3 else "", RESNET)
 WG = [(128, 128, 32), (64, 128, 32), (128, 64, 32), (64, 64, 32), (128, 128, 64), (64, 128, 64)]
 for shape in TABLE:
     H, W, Cin, Cout, (kh, kw), s, pads, _ = normalise(shape)
