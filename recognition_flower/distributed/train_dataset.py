@@ -70,6 +70,9 @@ flags.DEFINE_string("hip_graph", "auto", "on a GPU: replay the device part of th
                     "it; off for the collective modes, whose graph would hold the collectives as well)")
 flags.DEFINE_string("fault_inject", "", "Testing hook: 'exit_at_step:N' makes this worker die abruptly at global step N.")
 flags.DEFINE_boolean("shutdown_ps", True, "The chief stops the ps tasks when it finishes (the reference's ps never exits).")
+flags.DEFINE_integer("eval_batches", 8, "evaluator: batches of the record file evaluated per checkpoint.")
+flags.DEFINE_float("eval_poll_seconds", 0.5, "evaluator: pause between looks at checkpoint_dir.")
+flags.DEFINE_float("eval_timeout", 120.0, "evaluator: stop when no new checkpoint appeared for this many seconds.")
 flags.DEFINE_float("collective_timeout", 600.0, "Collective modes: seconds a rank waits inside a collective before the job "
                    "aborts (a lost rank must end the job so that a restart with --resume can take over).")
 flags.DEFINE_float("worker_timeout", 30.0, "Seconds of silence after which a worker no longer counts for the staleness bound.")
@@ -244,6 +247,67 @@ def _want_hip_graph() -> bool:
     raise ValueError("--hip_graph must be true, false or auto (got %r)" % FLAGS.hip_graph)
 
 
+def run_evaluator(spec):
+    """``evaluator`` replica of a TFJob: follows ``checkpoint_dir``, loads every new checkpoint into an
+    inference-mode model, measures loss / top-1 accuracy over ``--eval_batches`` batches of the record file and
+    writes them as summaries under ``<summaries_dir><model_version>/eval`` at the checkpoint's global step.
+    (The reference computes a held-out split and never evaluates it, recognition_flower/single/flower_train.py:105-106;
+    its distributed script has no evaluation at all.)  Ends when a checkpoint at or beyond ``--train_steps`` has
+    been evaluated, or when no new checkpoint appears for ``--eval_timeout`` seconds."""
+    from distributed_tensorflow_amd.io import bundle
+    from distributed_tensorflow_amd.io.events import EventWriter
+    from distributed_tensorflow_amd.io.saver import Saver
+    from distributed_tensorflow_amd.models import build_model
+    from distributed_tensorflow_amd.ops import functional as F
+
+    device = _device()
+    model_name = _model_name(device)
+    n_classes = _num_classes()
+    model = build_model(model_name, num_classes=n_classes, device=device).eval()
+    saver = Saver(model)
+    writer = EventWriter(os.path.join(FLAGS.summaries_dir + str(FLAGS.model_version), "eval"))
+    eval_params = dict(params, num_epochs=1)
+    seen, last_new = None, time.time()
+    while True:
+        prefix = bundle.latest_checkpoint(FLAGS.checkpoint_dir) if os.path.isdir(FLAGS.checkpoint_dir) else None
+        if prefix is None or prefix == seen:
+            if time.time() - last_new > FLAGS.eval_timeout:
+                print("Evaluator: no new checkpoint for %.0f s, stopping" % FLAGS.eval_timeout)
+                break
+            time.sleep(FLAGS.eval_poll_seconds)
+            continue
+        try:
+            step = saver.restore(prefix, restore_slots=False)
+        except Exception as e:  # noqa: BLE001 -- e.g. pruned by max_to_keep between listing and reading
+            print("Evaluator: skipping %s (%s: %s)" % (os.path.basename(prefix), type(e).__name__, e))
+            seen, last_new = prefix, time.time()
+            continue
+        seen, last_new = prefix, time.time()
+        data = train_input_fn(FLAGS.tfrecords_path, eval_params, device, 0, 1)
+        n = correct = 0
+        loss_sum = 0.0
+        with torch.no_grad():
+            for i, (x, y) in enumerate(data):
+                if i >= FLAGS.eval_batches:
+                    break
+                out = model(x)
+                logits = out[0] if isinstance(out, tuple) else out
+                xent, _, _, ok = F.softmax_xent(logits, y, n_classes)
+                loss_sum += float(xent.float().item()) * int(y.shape[0])
+                correct += int(ok.float().sum().item())
+                n += int(y.shape[0])
+        if hasattr(data, "close"):
+            data.close()
+        acc, loss = correct / max(n, 1), loss_sum / max(n, 1)
+        writer.add_summary(step, {"accuracy": acc, "loss": loss})
+        writer.flush()
+        print("Evaluator: global step %d accuracy %.4f loss %.4f (%d examples)" % (step, acc, loss, n), flush=True)
+        if step >= params["train_steps"]:
+            break
+    writer.close()
+    return 0
+
+
 def main(unused_argv):
     from distributed_tensorflow_amd.utils.cluster import parse_tf_config
 
@@ -251,8 +315,9 @@ def main(unused_argv):
     spec = parse_tf_config()
     if spec.task_type == "ps":
         return run_ps(spec)
+    if spec.task_type == "evaluator":
+        return run_evaluator(spec)
     if not spec.is_trainer:
-        # e.g. an "evaluator" replica of a TFJob: the reference has no evaluation loop to run there
         print("task type %r has no role in this trainer; exiting" % spec.task_type)
         return 0
     return run_worker(spec)

@@ -213,3 +213,32 @@ def test_run_sh_launches_ps_and_workers(tmp_path):
     assert r.returncode == 0, r.stdout
     assert r.stdout.count("finished training") == 2
     assert int(bundle.read_bundle(bundle.latest_checkpoint(str(tmp_path / "ckpt")))["global_step"]) >= 6
+
+
+def test_evaluator_replica_follows_checkpoints(tmp_path):
+    """A TFJob-style ``evaluator`` task next to a ps and a worker: it evaluates checkpoints as they appear, writes
+    eval summaries at their global steps and ends once the final checkpoint (train_steps) has been evaluated."""
+    import socket
+
+    from distributed_tensorflow_amd.io import events
+
+    def port():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+    cluster = {"ps": ["localhost:%d" % port()], "worker": ["localhost:%d" % port()], "evaluator": ["localhost:%d" % port()]}
+    common = ["train_dataset.py", "--synthetic", "--model=flower_cnn", "--image_size=32", "--batch_size=4",
+              "--train_steps=6", "--checkpoint_dir=%s/ckpt/" % tmp_path, "--summaries_dir=%s/events/" % tmp_path,
+              "--eval_batches=2", "--eval_timeout=60", "--eval_poll_seconds=0.1"]
+    procs = []
+    for task in ({"type": "ps", "index": 0}, {"type": "worker", "index": 0}, {"type": "evaluator", "index": 0}):
+        env = dict(os.environ, TF_CONFIG=json.dumps({"cluster": cluster, "task": task}))
+        procs.append(subprocess.Popen([sys.executable] + common, cwd=DIST, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0, 0], outs
+    steps = [int(m) for m in re.findall(r"Evaluator: global step (\d+) accuracy", outs[2])]
+    assert steps and steps[-1] == 6 and steps == sorted(steps), outs[2]
+    ev_files = glob.glob(str(tmp_path / "events" / "1" / "eval" / "events.out.tfevents.*"))
+    assert len(ev_files) == 1
+    evs = [e for e in events.read_events(ev_files[0]) if e.get("scalars")]
+    assert [e["step"] for e in evs] == steps and {"accuracy", "loss"} <= set(evs[-1]["scalars"])
