@@ -124,6 +124,10 @@ def test_global_avg_pool():
     dx = K.gap_bwd(dy.cuda(), x.shape)
     want = (dy.float() / 64)[:, None, None, :].expand(5, 8, 8, 2048)
     torch.testing.assert_close(dx.float().cpu(), want, rtol=1e-2, atol=1e-3)
+    # channel-group counts that are not powers of two, pixel counts that leave a tail behind the 4-deep unroll
+    for shape in ((3, 14, 14, 512), (2, 7, 7, 192), (4, 5, 3, 72), (1, 1, 1, 8), (2, 9, 9, 4096)):
+        x = _rand(*shape, seed=11)
+        torch.testing.assert_close(K.gap_fwd(x.cuda()).float().cpu(), x.float().mean((1, 2)), rtol=1e-2, atol=1e-2)
 
 
 @pytest.mark.parametrize("B,n,ld", [(32, 5, 8), (7, 1001, 1008), (64, 64, 64)])
