@@ -46,6 +46,15 @@ def main():
     for r in rows:
         print("| %d | %.0f | %.2f | %.1f %% |" % (r["n_gpus"], r["value"], r["ms_per_step"],
                                                 100.0 * r["value"] / (r["n_gpus"] * base)))
+    # the second model bench.py measures in the same run (flower CNN by default)
+    for name in (rows[0].get("also") or {}):
+        vals = [(r["n_gpus"], (r.get("also") or {}).get(name) or {}) for r in rows]
+        if any("value" not in v for _, v in vals):
+            continue
+        b = vals[0][1]["value"] / vals[0][0]
+        print("\n%s\n\n| GPUs | images/sec | ms/step | efficiency |\n|---:|---:|---:|---:|" % name)
+        for n, v in vals:
+            print("| %d | %.0f | %.2f | %.1f %% |" % (n, v["value"], v["ms_per_step"], 100.0 * v["value"] / (n * b)))
 
 
 if __name__ == "__main__":
