@@ -128,3 +128,30 @@ def test_record_input_prefetch_stream_matches_cpu_reader(tmp_path):
     for (gx, gy), (cx, cy) in zip(got, cpu):
         assert gy.tolist() == cy.tolist()
         np.testing.assert_allclose(gx[..., :3].numpy(), cx[..., :3].float().numpy(), atol=0.02)
+
+
+def test_device_prefetcher_hands_over_batches_in_order():
+    """Batches produced one ahead on the helper thread + copy stream arrive in production order, complete (the
+    consumer's stream waits for the producer's event), while the compute stream is kept busy."""
+    from distributed_tensorflow_amd.data.prefetch import DevicePrefetcher
+
+    state = {"k": 0}
+
+    def produce():
+        k = state["k"]
+        state["k"] += 1
+        host = torch.full((1 << 20,), float(k)).pin_memory()
+        x = host.to("cuda", non_blocking=True)
+        return x * 2 + 1, torch.tensor([k], device="cuda")
+
+    pf = DevicePrefetcher(produce, "cuda")
+    busy = torch.randn(2048, 2048, device="cuda")
+    for k in range(12):
+        busy = busy @ busy * 1e-3
+        x, y = pf.next()
+        assert int(y.item()) == k
+        assert float(x.min().item()) == float(x.max().item()) == 2.0 * k + 1
+    pf.close()
+    assert state["k"] >= 12
+    with pytest.raises(ValueError):
+        DevicePrefetcher(produce, "cpu")
