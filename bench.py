@@ -37,8 +37,9 @@ DEFAULT_BATCH = {"resnet50": 2048, "flower_cnn": 1024, "inception_v3_head": 256}
 IMAGE_SIZE = {"resnet50": 224, "flower_cnn": 224, "inception_v3_head": 299}
 
 
-def run_config(args, model_name, batch, device, rank, world):
+def run_config(args, model_name, batch, device, rank, world, mode=None):
     """W untimed + K timed complete training steps of one model; returns the whole-job images/s (max time over ranks)."""
+    mode = mode or args.mode
     size = IMAGE_SIZE[model_name]
     torch.manual_seed(1234)
     kw = {"trunk_bn": args.trunk_bn} if model_name == "inception_v3_head" else {}
@@ -49,7 +50,13 @@ def run_config(args, model_name, batch, device, rank, world):
     else:
         # a fixed synthetic batch with random labels: a small constant rate keeps the loss finite at any world size
         opt, lr, okw = "momentum", 0.02, {"momentum": 0.9, "weight_decay": 1e-4}
-    engine = DataParallelEngine(model, mode=args.mode, optimizer=opt, lr=lr, opt_kwargs=okw,
+        if mode == "async_ssp" and args.staleness > 0:
+            # gradients applied one step late under heavy-ball momentum mu: on a quadratic of curvature c the
+            # iteration w' = (1 + mu) w - (mu + lr c) w_prev is stable only for lr c < 1 - mu, against
+            # lr c < 2 (1 + mu) without the delay -- a 38x smaller range at mu = 0.9.  Measured on this fixed batch:
+            # 0.02 and 0.002 oscillate upwards, 0.0005 descends.
+            lr = lr / 40
+    engine = DataParallelEngine(model, mode=mode, optimizer=opt, lr=lr, opt_kwargs=okw,
                                 bucket_mb=args.bucket_mb, staleness=args.staleness, p2p_max_bytes=args.p2p_kb * 1024)
 
     # synthetic batch generated on the device (a 2048 x 224 x 224 host tensor per rank would cost seconds and GBs)
@@ -123,6 +130,8 @@ def main():
                     help="inception_v3_head: trunk batch-norm on batch statistics (reference) or frozen moving statistics")
     ap.add_argument("--also", default="flower_cnn",
                     help="second model measured after the headline one and reported under \"also\" ('' = none)")
+    ap.add_argument("--also_modes", default="sharded_ps,async_ssp",
+                    help="distribution modes the headline model is measured in as well, reported under \"also\" ('' = none)")
     ap.add_argument("--hip_graph", type=int, default=-1,
                     help="1: record the whole step (fwd, bwd, collectives, optimizer) in a HIP graph and replay it; "
                          "default: on for inception_v3_head (hundreds of short kernels per step), off otherwise")
@@ -145,10 +154,11 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE=%d; reporting WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
     head = run_config(args, args.model, args.batch or DEFAULT_BATCH[args.model], device, rank, world)
+    import gc
+
     also = {}
     if args.also and args.also != args.model:
         # the second model of the headline metric (flower CNN), same K / W, measured after the headline run
-        import gc
         gc.collect()
         torch.cuda.empty_cache()
         try:
@@ -156,6 +166,17 @@ def main():
             also = {args.also: {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "final_loss")}}
         except Exception as e:  # noqa: BLE001 -- the headline number stands on its own
             also = {args.also: {"error": "%s: %s" % (type(e).__name__, e)}}
+    # the headline model in the other two distribution modes (sharded parameter ownership: reduce-scatter +
+    # all-gather; staleness-bounded asynchronous updates), same batch, same K / W
+    for other in [m for m in args.also_modes.split(",") if m and m != args.mode and not args.hip_graph]:
+        gc.collect()
+        torch.cuda.empty_cache()
+        key = "%s/%s" % (args.model, other)
+        try:
+            r = run_config(args, args.model, head["per_gpu_batch"], device, rank, world, mode=other)
+            also[key] = {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "final_loss")}
+        except Exception as e:  # noqa: BLE001
+            also[key] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps({
             "metric": "train images/sec (whole node)",

@@ -25,7 +25,10 @@ node the same roles map onto RCCL collectives over xGMI:
     waits for communication of the current step and every replica sees the
     same, at most ``s``-steps-stale parameters (``s = 0`` degenerates to
     ``sync_dp``).  The bound is enforced by construction instead of by the
-    reference's unbounded races.
+    reference's unbounded races.  Stale gradients narrow the stable step-size
+    range, most of all under momentum (one step of delay with heavy-ball
+    momentum ``mu``: ``lr * curvature < 1 - mu`` instead of ``< 2 (1 + mu)``),
+    so this mode wants a correspondingly smaller rate than ``sync_dp``.
 
 Buckets are sized for the xGMI mesh: a ring collective moves ``bucket/N`` per
 link per step, so ``bucket_mb`` defaults to 32 MiB (4 MiB messages at N = 8)
