@@ -2,6 +2,7 @@
 # Hardware counters of every kernel of one training step, three rocprofv3 passes (counters are not multiplexed):
 #   a: matrix-core / wave / LDS activity (8 SQ counters)   b: bytes fetched from HBM   c: bytes written + L2 hits
 #   tools/pmc_step.sh <tag> <bench.py arguments...>      results: gpurun_out/pmc_step/<tag>_{a,b,c}
+#   (pass --also "" --also_modes "" to profile the headline configuration only)
 # Summarise with tools/pmc_step_summary.py gpurun_out/pmc_step/<tag>.
 set -e
 tag="$1"; shift
