@@ -39,7 +39,9 @@ MODEL_SERVICE = "tensorflow.serving.ModelService"
 
 class GrpcModelServer:
     def __init__(self, manager: ModelManager, batcher, host: str = "127.0.0.1", port: int = 8500,
-                 max_workers: int = 16, max_message_mb: int = 64):
+                 max_workers: int = 64, max_message_mb: int = 64):
+        # (handler threads only parse a request and wait for the batcher: their number bounds how many requests
+        # can be in flight towards one GPU batch, so it is at least the batcher's maximum batch)
         self.manager = manager
         self.batcher = batcher
         self.calls = {"Predict": 0, "Classify": 0, "GetModelMetadata": 0, "GetModelStatus": 0}
