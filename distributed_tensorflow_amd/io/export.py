@@ -149,6 +149,8 @@ class Servable:
         #: SignatureDefs as exported (saved_model.pb); exports older than that file carry them in the manifest only
         self.signature_def: Dict = read_signatures(export_path) if os.path.exists(pb) else self.manifest["signature_def"]
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         m = self.manifest["model"]
         self.model = build_model(m["name"], num_classes=m["num_classes"], device=self.device, **m["kwargs"])
         Saver(self.model).restore(os.path.join(export_path, "variables", "variables"), strict=True)
@@ -197,7 +199,8 @@ class Servable:
                 self.model(static_in)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # (thread-local: other threads of a server may issue HIP calls during the capture)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = self.model(static_in)
                 static_out = out[0] if isinstance(out, tuple) else out
             entry = self._graphs[bucket] = (graph, static_in, static_out)
