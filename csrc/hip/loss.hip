@@ -95,3 +95,77 @@ extern "C" int dtfa_mean_f32(const float* v, float* out, int n, float extra_scal
   hipLaunchKernelGGL(mean_f32_kernel, dim3(1), dim3(1024), 0, st, v, out, n, extra_scale);
   return (int)hipGetLastError();
 }
+
+// L2 activity regulariser on a bf16 activation (the reference applies l2_regularizer(0.0005) to the head's hidden
+// layer, recognition_flower/single/flower_train.py:77):  reg = coef/2 * sum(h^2).
+// Forward: up to 256 blocks write one partial each (fixed grid -> deterministic), block 0 of a second tiny launch
+// is avoided by letting mean_f32_kernel's caller fold the partials (n = number of blocks, extra_scale = n).
+__global__ void act_l2_partials_kernel(const bf16* __restrict__ h, long long n8, float half_coef, float* __restrict__ part) {
+  __shared__ float wsum[16];
+  float s = 0.f;
+  const bf16x8* hv = (const bf16x8*)h;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    bf16x8 v = hv[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)v[j];
+      s += f * f;
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wsum[w];
+    part[blockIdx.x] = t * half_coef;
+  }
+}
+
+// Backward, fused with the gradient that arrives from the layer above:  dh = dh_in + (coef * g) * h, where g is
+// the (device-resident) gradient of the loss with respect to the regulariser scalar.
+__global__ void act_l2_bwd_kernel(const bf16* __restrict__ h, const bf16* __restrict__ dh_in, const float* __restrict__ g,
+                                  float coef, bf16* __restrict__ dh, long long n8) {
+  const float c = coef * g[0];
+  const bf16x8* hv = (const bf16x8*)h;
+  const bf16x8* dv = (const bf16x8*)dh_in;
+  bf16x8* ov = (bf16x8*)dh;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    bf16x8 a = hv[i], o;
+    if (dh_in != nullptr) {
+      bf16x8 d = dv[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)d[j] + c * (float)a[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)(c * (float)a[j]);
+    }
+    ov[i] = o;
+  }
+}
+
+extern "C" int dtfa_act_l2_blocks(long long n) {
+  long long n8 = n / 8;
+  long long b = (n8 + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
+// part must hold dtfa_act_l2_blocks(n) floats; out[0] receives the regulariser.  n % 8 == 0.
+extern "C" int dtfa_act_l2_fwd(const void* h, long long n, float coef, float* part, float* out, hipStream_t st) {
+  if (n <= 0 || n % 8 != 0) return -1;
+  int blocks = dtfa_act_l2_blocks(n);
+  hipLaunchKernelGGL(act_l2_partials_kernel, dim3(blocks), dim3(256), 0, st, (const bf16*)h, n / 8, 0.5f * coef, part);
+  hipLaunchKernelGGL(mean_f32_kernel, dim3(1), dim3(256), 0, st, (const float*)part, out, blocks, (float)blocks);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dtfa_act_l2_bwd(const void* h, const void* dh_in, const float* g, float coef, void* dh, long long n,
+                               hipStream_t st) {
+  if (n <= 0 || n % 8 != 0) return -1;
+  long long n8 = n / 8;
+  long long blocks = (n8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(act_l2_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)h, (const bf16*)dh_in, g,
+                     coef, (bf16*)dh, n8);
+  return (int)hipGetLastError();
+}

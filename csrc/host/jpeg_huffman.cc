@@ -25,13 +25,18 @@ struct Huff {
   int mincode[17], maxcode[18], valptr[17];
   // 9-bit fast path: (length << 8) | value, 0 = not resolvable in 9 bits
   uint16_t fast[512];
-  void build(const uint8_t* bits, const uint8_t* v, int nvals) {
+  // False for a code-length histogram that is not a prefix code (more codes of some length than that length has
+  // left: Kraft sum > 1).  Such a table would index ``fast`` past its end.
+  bool build(const uint8_t* bits, const uint8_t* v, int nvals) {
+    present = false;
+    if (nvals < 0 || nvals > 256) return false;
     memcpy(vals, v, nvals);
     int code = 0, k = 0;
     memset(fast, 0, sizeof(fast));
     for (int l = 1; l <= 16; ++l) {
       valptr[l] = k;
       mincode[l] = code;
+      if (code + (int)bits[l] > (1 << l) || k + (int)bits[l] > nvals) return false;
       for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
         if (l <= 9) {
           int lo = code << (9 - l), hi = lo + (1 << (9 - l));
@@ -43,6 +48,7 @@ struct Huff {
     }
     maxcode[17] = 0x7fffffff;
     present = true;
+    return true;
   }
 };
 
@@ -52,9 +58,11 @@ struct BitReader {
   uint64_t buf = 0;
   int cnt = 0;
   bool hit_marker = false;
+  int pad_bytes = 0;  // zero bytes fed after the end of the entropy-coded data
   void fill() {
     while (cnt <= 56) {
       uint8_t b = 0;
+      if (hit_marker || p >= end) ++pad_bytes;
       if (!hit_marker && p < end) {
         b = *p;
         if (b == 0xff) {
@@ -85,6 +93,7 @@ struct BitReader {
     buf = 0;
     cnt = 0;
     hit_marker = false;
+    pad_bytes = 0;
   }
 };
 
@@ -124,7 +133,12 @@ struct DtfaJpegInfo {
   int sof;                        // SOF marker type (0 = baseline, 1 = extended sequential, 2 = progressive, ...)
 };
 
-// error codes: -1 malformed, -2 unsupported coding (progressive / arithmetic / 12-bit / >4 components)
+// Largest image accepted (pixels).  The header alone sizes the coefficient buffer, so an unchecked 65535 x 65535
+// header would make a server allocate ~25 GB of pinned memory for a few bytes of input.
+const long long kMaxPixels = 1ll << 26;
+
+// error codes: -1 malformed, -2 unsupported coding (progressive / arithmetic / 12-bit / >4 components),
+// -3 coefficient buffer too small, -4 image larger than kMaxPixels
 static int parse(const uint8_t* d, size_t n, DtfaJpegInfo* info, Huff dc[4], Huff ac[4], int comp_dc[4], int comp_ac[4],
                  const uint8_t** scan, uint16_t qtab[4][64], int comp_tq[4], bool want_scan) {
   if (n < 4 || d[0] != 0xff || d[1] != 0xd8) return -1;
@@ -169,6 +183,7 @@ static int parse(const uint8_t* d, size_t n, DtfaJpegInfo* info, Huff dc[4], Huf
       info->ncomp = s[5];
       if (info->ncomp < 1 || info->ncomp > 4 || sl < 6 + 3 * (size_t)info->ncomp) return -2;
       if (info->width <= 0 || info->height <= 0) return -1;
+      if ((long long)info->width * info->height > kMaxPixels) return -4;
       for (int c = 0; c < info->ncomp; ++c) {
         comp_id[c] = s[6 + 3 * c];
         info->hs[c] = s[7 + 3 * c] >> 4;
@@ -193,7 +208,7 @@ static int parse(const uint8_t* d, size_t n, DtfaJpegInfo* info, Huff dc[4], Huf
         }
         q += 17;
         if (total > 256 || q + total > sl) return -1;
-        (tc ? ac : dc)[th].build(bits, s + q, total);
+        if (!(tc ? ac : dc)[th].build(bits, s + q, total)) return -1;
         q += total;
       }
     } else if (m == 0xdd) {  // DRI
@@ -307,6 +322,9 @@ int dtfa_jpeg_decode_coefs(const uint8_t* data, uint64_t n, DtfaJpegInfo* info, 
         }
       }
       ++count;
+      // the reader feeds zeros past the end of the data; a few bytes of look-ahead are normal, an MCU decoded
+      // entirely from padding means the scan is truncated
+      if (br.pad_bytes > 32) return -1;
     }
   }
   return 0;

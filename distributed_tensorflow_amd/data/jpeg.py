@@ -91,6 +91,18 @@ def reconstruct_reference(info, coefs: np.ndarray) -> np.ndarray:
     return np.clip(np.rint(rgb), 0, 255).astype(np.uint8)
 
 
+class JpegDecodeError(ValueError):
+    """An image of a batch that neither the native decoder nor PIL accepts; ``index`` is its position."""
+
+    def __init__(self, index: int, why: str):
+        super().__init__("image %d of the batch cannot be decoded: %s" % (index, why))
+        self.index = index
+
+
+# Upper bound on the DCT coefficients staged for one batch (int16 each): 1 Gi coefficients = 2 GiB of pinned
+# memory, ~64 images of 16 Mpixel.  Headers are client-controlled, so the sum is checked before allocating.
+MAX_BATCH_COEFS = int(os.environ.get("DTFA_JPEG_MAX_BATCH_COEFS", str(1 << 30)))
+
 _pool: Optional[ThreadPoolExecutor] = None
 _pool_size = 0
 
@@ -165,6 +177,8 @@ def decode_batch_to_device(jpegs: Sequence[bytes], device, threads: Optional[int
         infos.append(info)
         coef_off[i] = coef_pos
         coef_pos += (info.total_coefs + 7) // 8 * 8
+        if coef_pos > MAX_BATCH_COEFS:
+            raise JpegDecodeError(i, "the batch exceeds %d DCT coefficients" % MAX_BATCH_COEFS)
     staging, ring, turn = _coef_staging(device, coef_pos)
     base = staging.data_ptr()
 
@@ -182,7 +196,10 @@ def decode_batch_to_device(jpegs: Sequence[bytes], device, threads: Optional[int
     fallback = {}
     for i in range(n):
         if not ok[i]:
-            img = decode_pil(jpegs[i])
+            try:
+                img = decode_pil(jpegs[i])
+            except Exception as e:  # noqa: BLE001 -- PIL raises several unrelated types on malformed files
+                raise JpegDecodeError(i, "%s: %s" % (type(e).__name__, e)) from None
             fallback[i] = img
             h, w = img.shape[:2]
         else:

@@ -205,6 +205,9 @@ class Saver:
         self.wait()
         os.makedirs(checkpoint_dir, exist_ok=True)
         tensors = self.variables(detach_host=background)
+        fetched = getattr(self.engine, "fetched_global_step", None)
+        if fetched is not None:
+            global_step = fetched  # asynchronous ps: label the files with the step the fetched state belongs to
         tensors["global_step"] = np.array(int(global_step), dtype=np.int64)
         opt = getattr(self.engine, "optimizer", None)
         if opt is not None and getattr(opt, "beta1_power", None) is not None:
@@ -276,19 +279,21 @@ class Saver:
                     t.copy_(new.to(device=t.device, dtype=t.dtype))
         if strict and missing:
             raise KeyError("variables missing from checkpoint: %s" % missing[:5])
-        if self.engine is not None:
-            if touched_master:
-                self.engine.load_master()
-            if new_slots:
-                self.engine.load_full_slots(new_slots)
         step = 0
         for key in ("global_step", "Variable"):
             if key in data:
                 step = int(np.asarray(data[key]).reshape(-1)[0])
                 break
+        # the step count first: a parameter-server engine uploads it together with the variables (it is also
+        # what Adam's beta powers are derived from)
         opt = getattr(self.engine, "optimizer", None)
         if opt is not None:
             opt.step_count = step
+        if self.engine is not None:
+            if touched_master:
+                self.engine.load_master()
+            if new_slots:
+                self.engine.load_full_slots(new_slots)
         return step
 
     def restore_latest(self, checkpoint_dir: str, **kw) -> Optional[int]:

@@ -36,7 +36,7 @@ class FlowerHead(nn.Module):
         h = self.dense_prelogit1(feats)
         reg = None
         if self.act_l2:
-            reg = 0.5 * self.act_l2 * (h.float() ** 2).sum()
+            h, reg = F.activity_l2(h, self.act_l2)
         h = F.dropout(h, self.dropout_rate, self.training)
         logits = self.flower_logits(h)
         return logits, reg

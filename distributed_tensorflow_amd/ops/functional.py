@@ -641,13 +641,46 @@ def dropout(x, rate: float, training: bool, seed: Optional[int] = None):
 
 
 # ----------------------------------------------------------------------------
+# activity regulariser
+# ----------------------------------------------------------------------------
+class _ActL2Fn(Function):
+    """``(h, coef/2 * sum(h^2))``: the activation passes through, so that its two gradients -- from the layers
+    above and from the regulariser -- are combined in one kernel instead of autograd's separate multiply and add."""
+
+    @staticmethod
+    def forward(ctx, h, coef):
+        ctx.coef = coef
+        ctx.save_for_backward(h)
+        return h.view_as(h), K.act_l2_fwd(h, coef)[0]
+
+    @staticmethod
+    def backward(ctx, dh, dreg):
+        (h,) = ctx.saved_tensors
+        if dreg is None:
+            return dh, None
+        g = dreg.detach().reshape(1).to(F32)
+        return K.act_l2_bwd(h, dh.contiguous() if dh is not None else None, g, ctx.coef), None
+
+
+def activity_l2(h, coef: float):
+    """L2 activity regulariser of the reference's head (``l2_regularizer(coef)(h)`` = ``coef * sum(h^2) / 2`` over
+    the whole batch; recognition_flower/single/flower_train.py:71,77).  Returns ``(h, reg)``: use the returned
+    ``h`` downstream."""
+    if not _use_hip(h) or h.numel() % 8 or not h.is_contiguous():
+        return h, 0.5 * coef * (h.float() ** 2).sum()
+    return _ActL2Fn.apply(h, coef)
+
+
+# ----------------------------------------------------------------------------
 # loss
 # ----------------------------------------------------------------------------
 class _XentFn(Function):
     @staticmethod
     def forward(ctx, logits, labels, n_classes, act_l2):
         B = logits.shape[0]
-        loss, dl, top1, score, correct = K.softmax_xent(logits, labels, n_classes, 1.0 / B, act_l2)
+        # the kernel folds the activity term into the per-row loss, which is then averaged: B * act_l2 per row
+        # makes it the batch SUM the regulariser is defined as
+        loss, dl, top1, score, correct = K.softmax_xent(logits, labels, n_classes, 1.0 / B, act_l2 * B)
         ctx.save_for_backward(dl)
         ctx.mark_non_differentiable(top1, score, correct)
         return K.mean_f32(loss)[0], top1, score, correct
@@ -660,10 +693,12 @@ class _XentFn(Function):
 
 
 def softmax_xent(logits, labels, n_classes: Optional[int] = None, act_l2: float = 0.0):
-    """Mean sparse softmax cross-entropy (+ optional L2 activity term on the
-    logits).  Returns ``(loss, top1, top1_score, correct)``."""
+    """Mean sparse softmax cross-entropy, plus ``act_l2 * sum(logits**2) / 2`` over the WHOLE batch: the
+    reference adds ``l2_regularizer(0.0005)(flower_logits)`` = ``0.0005 * tf.nn.l2_loss(logits)``, a batch sum,
+    un-averaged, to ``reduce_mean(xent)`` (recognition_flower/single/flower_train.py:84,143-145).
+    Returns ``(loss, top1, top1_score, correct)``."""
     n = n_classes if n_classes is not None else logits.shape[-1]
     if not _use_hip(logits):
-        loss, top1, score, correct = ref.softmax_xent(logits, labels, n, act_l2)
+        loss, top1, score, correct = ref.softmax_xent(logits, labels, n, act_l2 * logits.shape[0])
         return loss.mean(), top1, score, correct
     return _XentFn.apply(logits.contiguous(), labels.to(torch.int32).contiguous(), n, act_l2)

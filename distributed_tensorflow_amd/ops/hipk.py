@@ -108,6 +108,9 @@ class _Sigs:
     dtfa_softmax_xent = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_float,
                          c_float, c_void]
     dtfa_mean_f32 = [c_void, c_void, c_int, c_float, c_void]
+    dtfa_act_l2_blocks = [c_ll]
+    dtfa_act_l2_fwd = [c_void, c_ll, c_float, c_void, c_void, c_void]
+    dtfa_act_l2_bwd = [c_void, c_void, c_void, c_float, c_void, c_ll, c_void]
     dtfa_adam = [c_void, c_void, c_void, c_void, c_int, c_void, c_ll, c_void, c_float, c_float, c_float, c_void]
     dtfa_momentum = [c_void, c_void, c_void, c_int, c_void, c_ll, c_void, c_float, c_float, c_int, c_void]
     dtfa_cast_f32_bf16 = [c_void, c_void, c_ll, c_void]

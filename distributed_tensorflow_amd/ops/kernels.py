@@ -392,6 +392,35 @@ def softmax_xent(logits: torch.Tensor, labels: torch.Tensor, n_classes: int, gra
     return loss, dl, top1, score, correct
 
 
+def act_l2_fwd(h: torch.Tensor, coef: float) -> torch.Tensor:
+    """``coef / 2 * sum(h**2)`` of a bf16 activation as an fp32 scalar tensor [1] (two launches, fixed grid)."""
+    hipk.require(h, BF16, "h")
+    n = h.numel()
+    if n == 0 or n % 8:
+        raise ValueError("activity L2: element count must be a positive multiple of 8")
+    L = hipk.lib()
+    part = torch.empty(L.dtfa_act_l2_blocks(n), dtype=F32, device=h.device)
+    out = torch.empty(1, dtype=F32, device=h.device)
+    hipk.check(L.dtfa_act_l2_fwd(h.data_ptr(), n, float(coef), part.data_ptr(), out.data_ptr(), hipk.stream()), "act_l2_fwd")
+    return out
+
+
+def act_l2_bwd(h: torch.Tensor, dh_in: Optional[torch.Tensor], g: torch.Tensor, coef: float) -> torch.Tensor:
+    """``dh_in + coef * g * h`` in one pass (``dh_in`` may be None); ``g`` is an fp32 device scalar."""
+    hipk.require(h, BF16, "h")
+    hipk.require(g, F32, "g")
+    if dh_in is not None:
+        hipk.require(dh_in, BF16, "dh_in")
+        if dh_in.numel() != h.numel():
+            raise ValueError("activity L2 backward: gradient / activation size mismatch")
+    if g.numel() != 1 or h.numel() % 8:
+        raise ValueError("activity L2 backward shapes")
+    out = torch.empty_like(h)
+    hipk.check(hipk.lib().dtfa_act_l2_bwd(h.data_ptr(), hipk.ptr(dh_in), g.data_ptr(), float(coef), out.data_ptr(),
+                                          h.numel(), hipk.stream()), "act_l2_bwd")
+    return out
+
+
 def mean_f32(v: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     hipk.require(v, F32, "v")
     out = torch.empty(1, dtype=F32, device=v.device)

@@ -91,6 +91,9 @@ class DataParallelEngine:
             # version counter of every ring slot: the step whose gradient it holds.  DTFA_DEBUG_STALENESS=1
             # asserts at every apply that the gradient is exactly ``staleness`` steps old.
             self._ring_version: List[int] = [-1] * (self.staleness + 1)
+            # first step whose gradient has not been applied yet (``drain`` applies ahead of schedule and moves
+            # this forward, so that ``finish_step`` never applies a staged gradient a second time)
+            self._applied_through = 0
             self._debug_staleness = os.environ.get("DTFA_DEBUG_STALENESS") == "1"
         # buckets up to ``p2p_max_bytes`` skip RCCL and use the one-shot xGMI mailbox all-reduce
         self._p2p = None
@@ -234,7 +237,7 @@ class DataParallelEngine:
                 for g in self.flat.groups:
                     self._ring[slot][g.name].copy_(g.grad)
             self._ring_version[slot] = self._step
-            if self._step >= s:
+            if self._step - s >= self._applied_through:
                 apply_slot = (self._step - s) % (s + 1)
                 if self._debug_staleness and self._ring_version[apply_slot] != self._step - s:
                     raise AssertionError("staleness violation: applying the gradient of step %d at step %d (bound %d)"
@@ -245,6 +248,7 @@ class DataParallelEngine:
                 for r in self.optimizer.regions:
                     r.g = self._ring[apply_slot][r.name]
                 self.optimizer.step(grad_scale=scale)
+                self._applied_through = self._step - s + 1
         else:
             for h in self._handles:
                 h.wait()
@@ -254,12 +258,13 @@ class DataParallelEngine:
             self._step += 1
 
     def drain(self) -> None:
-        """Apply every gradient still in flight (async mode), e.g. before a checkpoint."""
+        """Apply every gradient still in flight (async mode), e.g. before a checkpoint.  Collective: every rank
+        must call it at the same step, or the replicas apply the same gradients at different times and diverge
+        (``TrainingSession`` therefore runs the checkpoint hook on all ranks in this mode)."""
         if self.mode != "async_ssp" or self.staleness == 0:
             return
         s = self.staleness
-        first = max(0, self._step - s)
-        for t in range(first, self._step):
+        for t in range(self._applied_through, self._step):
             slot = t % (s + 1)
             for h in self._ring_handles[slot]:
                 h.wait()
@@ -267,6 +272,7 @@ class DataParallelEngine:
             for r in self.optimizer.regions:
                 r.g = self._ring[slot][r.name]
             self.optimizer.step(grad_scale=1.0 / self.world)
+        self._applied_through = self._step
 
     def _gather_params(self) -> None:
         handles = []

@@ -158,6 +158,18 @@ class ParameterServer:
                     return
                 self.lock.wait(timeout=0.05)
 
+    def _load_slots(self, names, blob, n: int) -> None:
+        """Optimizer slots from a state message: ``names[i]`` (a slot kind such as ``Adam`` / ``Adam_1`` /
+        ``Momentum``, optionally followed by ``/<region>``) is stored in ``blob[(i+1)*n:(i+2)*n]``."""
+        slots = self.optimizer.slots()
+        by_kind = {k.rsplit("/", 1)[0]: v for k, v in slots.items()}
+        for i, k in enumerate(names):
+            dst = slots.get(k)
+            if dst is None:
+                dst = by_kind.get(k.rsplit("/", 1)[0] if "/" in k else k)
+            if dst is not None and blob.size >= (i + 2) * n:
+                dst.copy_(torch.from_numpy(blob[(i + 1) * n:(i + 2) * n].copy()))
+
     # -- request handling --------------------------------------------------------
     def _handle(self, conn: socket.socket) -> None:
         worker = -1
@@ -180,9 +192,11 @@ class ParameterServer:
                     meta_len = struct.unpack("<I", bytes(payload[:4]))[0]
                     meta = json.loads(bytes(payload[4:4 + meta_len]).decode())
                     blob = np.frombuffer(payload, dtype=np.float32, offset=4 + meta_len).copy()
+                    nslots = len(meta.get("slots", []))
+                    n_par = blob.size // (1 + nslots)
                     with self.lock:
                         if not self.initialized:  # first initialiser wins; later ones are ignored
-                            self.params = torch.from_numpy(blob)
+                            self.params = torch.from_numpy(blob[:n_par])
                             self.grad = torch.zeros_like(self.params)
                             self.optimizer = make_optimizer(meta.get("optimizer", "adam"),
                                                             [OptRegion("ps%d" % self.ps_index, self.params, self.grad,
@@ -190,6 +204,8 @@ class ParameterServer:
                                                             float(meta.get("lr", 1e-3)), **meta.get("opt_kwargs", {}))
                             self.global_step = int(meta.get("global_step", 0))
                             self.optimizer.step_count = self.global_step
+                            if nslots:  # a resumed run: the chief hands over the restored optimizer state too
+                                self._load_slots(meta["slots"], blob, n_par)
                             self.initialized = True
                             self.lock.notify_all()
                     _send_msg(conn, op, worker, ST_OK, self.global_step)
@@ -259,10 +275,7 @@ class ParameterServer:
                             continue
                         n = self.params.numel()
                         self.params.copy_(torch.from_numpy(blob[:n].copy()))
-                        slots = self.optimizer.slots()
-                        for i, k in enumerate(meta.get("slots", [])):
-                            if k in slots:
-                                slots[k].copy_(torch.from_numpy(blob[(i + 1) * n:(i + 2) * n].copy()))
+                        self._load_slots(meta.get("slots", []), blob, n)
                         self.global_step = int(meta.get("global_step", self.global_step))
                         self.optimizer.step_count = self.global_step
                     _send_msg(conn, op, worker, ST_OK, self.global_step)
@@ -382,7 +395,11 @@ class PSWorkerEngine:
 
     def __init__(self, model, ps_addresses: List[Tuple[str, int]], worker_index: int, is_chief: bool, *,
                  optimizer: str = "adam", lr: float = 1e-3, opt_kwargs: Optional[dict] = None,
-                 connect_timeout: float = 60.0, initial_global_step: int = 0):
+                 connect_timeout: float = 60.0, initial_global_step: int = 0, defer_init: bool = False):
+        """``defer_init`` (chief only): connect, but leave the ps tasks uninitialised until :meth:`initialize`,
+        so that a checkpoint can be restored into this engine first and the ps tasks start from the restored
+        variables, optimizer slots and global step -- non-chief workers blocked in ``wait_init`` never see the
+        un-restored values."""
         from .flat import FlatParams
 
         self.model = model
@@ -415,16 +432,48 @@ class PSWorkerEngine:
         self.conns = [_Conn(h, p, worker_index, connect_timeout) for h, p in ps_addresses]
         for c in self.conns:
             c.call(OP_HELLO, 0)
-        if is_chief:
+        self.initialized = False
+        self._pending_slots: Dict[str, torch.Tensor] = {}
+        self._cached_slots = None
+        self._cached_info: dict = {}
+        if not (defer_init and is_chief):
+            self.initialize()
+
+    def _slot_kinds(self) -> List[str]:
+        return ["Adam", "Adam_1"] if self._optimizer_name.lower() == "adam" else ["Momentum"]
+
+    def _pack_slot(self, ps: int, full: torch.Tensor) -> np.ndarray:
+        """The part of a full-layout slot tensor (keyed by flat group) that lives on ps task ``ps``."""
+        parts = [full[g.name][s.offset:s.offset + s.numel].detach().float().cpu().numpy() for g, s in self.placement[ps]]
+        return np.concatenate(parts) if parts else np.zeros(0, np.float32)
+
+    def _state_payload(self, ps: int, slots: Dict[str, torch.Tensor], extra_meta: dict) -> bytes:
+        """``<meta><params><slot 0><slot 1>..`` for ps task ``ps``; ``slots`` is keyed ``<kind>/<group>``."""
+        kinds = [k for k in self._slot_kinds() if all((k + "/" + g.name) in slots for g in self.flat.groups)]
+        meta = dict(extra_meta, slots=kinds, global_step=int(self.global_step))
+        blobs = [self._pack(ps, "master").tobytes()]
+        for k in kinds:
+            blobs.append(self._pack_slot(ps, {g.name: slots[k + "/" + g.name] for g in self.flat.groups}).tobytes())
+        m = json.dumps(meta).encode()
+        return struct.pack("<I", len(m)) + m + b"".join(blobs)
+
+    def initialize(self) -> None:
+        """Chief: upload the initial (or restored) variables, optimizer slots and global step -- exactly once per
+        run; everybody else waits until that has happened.  Then the first pull."""
+        if self.initialized:
+            return
+        if self.is_chief:
             for i, c in enumerate(self.conns):
-                meta = json.dumps({"optimizer": optimizer, "lr": lr, "opt_kwargs": self._opt_kwargs,
-                                   "global_step": initial_global_step}).encode()
-                c.call(OP_INIT, 0, struct.pack("<I", len(meta)) + meta + self._pack(i, "master").tobytes())
+                payload = self._state_payload(i, self._pending_slots, {"optimizer": self._optimizer_name, "lr": self.lr,
+                                                                       "opt_kwargs": self._opt_kwargs})
+                c.call(OP_INIT, 0, payload)
+            self._pending_slots = {}
         else:
             for c in self.conns:
                 st, _, _ = c.call(OP_WAIT_INIT, 0)
                 if st != ST_OK:
                     raise ConnectionError("parameter server stopped before initialisation")
+        self.initialized = True
         self.pull()
 
     def current_lr(self) -> float:
@@ -512,8 +561,6 @@ class PSWorkerEngine:
         self.clock += 1
         return self.global_step
 
-    def drain(self) -> None:
-        pass
 
     def status(self) -> dict:
         _, _, data = self.conns[0].call(OP_STATUS, self.clock)
@@ -551,6 +598,12 @@ class PSWorkerEngine:
         return masters, slots, info
 
     def full_master(self):
+        if not self.initialized:  # deferred initialisation: nothing on the ps yet, the local values are the state
+            self._cached_slots = {k + "/" + g.name: torch.zeros_like(g.master) for k in self._slot_kinds()
+                                  for g in self.flat.groups}
+            self._cached_slots.update(self._pending_slots)
+            self._cached_info = {}
+            return {g.name: g.master for g in self.flat.groups}
         masters, slots, info = self._fetch_state()
         self._cached_slots, self._cached_info = slots, info
         for g in self.flat.groups:
@@ -572,16 +625,30 @@ class PSWorkerEngine:
     def beta2_power(self):
         return (getattr(self, "_cached_info", {}) or {}).get("beta2_power")
 
+    @property
+    def fetched_global_step(self) -> Optional[int]:
+        """Global step of the state last fetched from the ps tasks (what a checkpoint of it must be labelled
+        with: other workers keep stepping between this worker's update and the fetch)."""
+        gs = (self._cached_info or {}).get("global_step")
+        return int(gs) if gs is not None else None
+
     def load_master(self) -> None:
-        """Push restored master values (``FlatGroup.master``) back to the ps tasks."""
-        for i, c in enumerate(self.conns):
-            meta = json.dumps({"slots": [], "global_step": self.global_step}).encode()
-            c.call(OP_SET_STATE, self.clock, struct.pack("<I", len(meta)) + meta + self._pack(i, "master").tobytes())
+        """Push restored master values (``FlatGroup.master``) and the restored global step to the ps tasks
+        (after initialisation; before it the values simply wait for :meth:`initialize`)."""
+        if self.initialized:
+            for i, c in enumerate(self.conns):
+                c.call(OP_SET_STATE, self.clock, self._state_payload(i, {}, {}))
         for g in self.flat.groups:
             g.sync_compute_from_master()
 
     def load_full_slots(self, full) -> None:
-        pass  # optimizer slots are re-created on the ps; restoring them is not supported over the wire yet
+        """Restored optimizer slots (full layout, keyed ``<kind>/<group>``) to their ps tasks, together with the
+        variables and the global step (Adam's ``beta*_power`` follow from the step count on the ps)."""
+        if not self.initialized:
+            self._pending_slots = {k: v.detach().clone() for k, v in full.items()}
+            return
+        for i, c in enumerate(self.conns):
+            c.call(OP_SET_STATE, self.clock, self._state_payload(i, full, {}))
 
     @property
     def step_count(self):

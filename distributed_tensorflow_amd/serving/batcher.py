@@ -42,6 +42,7 @@ class DynamicBatcher:
         self.items = 0
         self.requests = 0
         self.rejected = 0
+        self.split_batches = 0   # merged batches that failed and were re-run request by request
         self.busy_seconds = 0.0
         self.wait_seconds = 0.0
         self._thread = threading.Thread(target=self._loop, name=name, daemon=True)
@@ -106,8 +107,18 @@ class DynamicBatcher:
                 parts = [self.fn(flat[i:i + self.max_batch]) for i in range(0, len(flat), self.max_batch)]
                 out = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
             except BaseException as e:  # noqa: BLE001 -- every caller of this batch must be released
-                for _, fut, _ in batch:
-                    fut.set_exception(e)
+                if len(batch) == 1:
+                    batch[0][1].set_exception(e)
+                else:
+                    # one bad item (an undecodable image) must not fail the other clients merged into the same
+                    # device batch: run the requests one by one, only the offending ones get the exception
+                    self.split_batches += 1
+                    for items, fut, _ in batch:
+                        try:
+                            ps = [self.fn(items[i:i + self.max_batch]) for i in range(0, len(items), self.max_batch)]
+                            fut.set_result({k: np.concatenate([q[k] for q in ps], axis=0) for k in ps[0]})
+                        except BaseException as e1:  # noqa: BLE001
+                            fut.set_exception(e1)
                 continue
             t1 = time.monotonic()
             self.batches += len(parts)

@@ -46,6 +46,29 @@ class Hook:
         pass
 
 
+class EveryNSteps:
+    """Trigger for "every ``n`` global steps" that also works when the observed step sequence has gaps.
+
+    With several asynchronous workers the global step a worker sees after its own update advances by more
+    than one (other workers stepped meanwhile); a ``step % n == 0`` test then never fires for a worker that
+    keeps seeing odd steps.  Like TensorFlow's step timer (the hooks of
+    recognition_flower/distributed/train_dataset.py:176-180) the trigger fires when a multiple of ``n`` has
+    been reached or passed since the last time it fired; on a gap-free sequence that is exactly every
+    multiple of ``n``."""
+
+    def __init__(self, n: int):
+        self.n = max(1, int(n))
+        self.last = None  # last step the trigger looked at
+
+    def reset(self, step: int) -> None:
+        self.last = int(step)
+
+    def __call__(self, step: int) -> bool:
+        prev = self.last if self.last is not None else step - 1
+        self.last = int(step)
+        return step // self.n > prev // self.n
+
+
 class StopAtStepHook(Hook):
     def __init__(self, last_step: int):
         self.last_step = last_step
@@ -61,10 +84,13 @@ class LoggingHook(Hook):
     recognition_flower/distributed/train_dataset.py:190-191)."""
 
     def __init__(self, every_n_steps: int = 1, worker_index: Optional[int] = None, printer: Callable = print):
-        self.every, self.worker_index, self.printer = max(1, every_n_steps), worker_index, printer
+        self.every, self.worker_index, self.printer = EveryNSteps(every_n_steps), worker_index, printer
+
+    def begin(self, session):
+        self.every.reset(session.global_step)
 
     def after_step(self, session, r):
-        if r.global_step % self.every:
+        if not self.every(r.global_step):
             return
         if self.worker_index is None:
             self.printer("step %d: learning rate %.6f accuracy %.4f loss %.6f (%.1f images/sec)" % (
@@ -113,9 +139,13 @@ class CheckpointSaverHook(Hook):
         self.dir, self.save_steps, self.saver, self.save_at_end = checkpoint_dir, max(1, save_steps), saver, save_at_end
         self.background = background
         self.last_saved = -1
+        self._due = EveryNSteps(self.save_steps)
+
+    def begin(self, session):
+        self._due.reset(session.global_step)
 
     def after_step(self, session, r):
-        if r.global_step % self.save_steps == 0 and r.global_step != self.last_saved:
+        if self._due(r.global_step) and r.global_step != self.last_saved:
             session.save_checkpoint(self.saver, self.dir, r.global_step, background=self.background)
             self.last_saved = r.global_step
 
@@ -134,6 +164,7 @@ class SummarySaverHook(Hook):
 
     def __init__(self, save_steps: int, output_dir: str, histogram: bool = True):
         self.save_steps = max(1, save_steps)
+        self._due = EveryNSteps(self.save_steps)
         self.output_dir = output_dir
         self.writer = None  # opened in begin(): hooks dropped on non-chief ranks never create a file
         self.histogram = histogram
@@ -143,9 +174,10 @@ class SummarySaverHook(Hook):
 
         if self.writer is None:
             self.writer = EventWriter(self.output_dir)
+        self._due.reset(session.global_step)
 
     def after_step(self, session, r):
-        if r.global_step % self.save_steps:
+        if not self._due(r.global_step):
             return
         scalars = {"loss": r.loss, "accuracy": r.accuracy, "learning_rate": r.learning_rate}
         scalars.update({k: float(v) for k, v in r.extra.items() if isinstance(v, (int, float))})
@@ -217,7 +249,11 @@ class TrainingSession:
         self.model, self.engine = model, engine
         self.num_classes = num_classes
         self.is_chief = is_chief
-        needs_all_ranks = getattr(engine, "mode", "") == "sharded_ps" and getattr(engine, "world", 1) > 1
+        # sharded ownership: every rank joins the gathers of a save; delayed-apply async: every rank must drain
+        # its in-flight gradients at the same step as the chief
+        needs_all_ranks = getattr(engine, "world", 1) > 1 and (
+            getattr(engine, "mode", "") == "sharded_ps"
+            or (getattr(engine, "mode", "") == "async_ssp" and getattr(engine, "staleness", 0) > 0))
         self.hooks = [h for h in (hooks or [])
                       if is_chief or not h.chief_only or (needs_all_ranks and getattr(h, "collective", False))]
         self.reg_weight, self.logits_act_l2 = reg_weight, logits_act_l2
@@ -307,7 +343,10 @@ class TrainingSession:
             self.engine.finish_step()
             self._eager_steps += 1
         total, xent, logits, top1, score, correct = out
-        self.global_step += 1
+        # a parameter-server engine reports the shared global step its update produced (other workers advance it
+        # too); the collective engines count one per step
+        shared = getattr(self.engine, "global_step", None)
+        self.global_step = int(shared) if shared is not None else self.global_step + 1
         # one device-to-host transfer for the three scalars; it synchronises with the device, so step_time covers
         # the whole step
         loss_v, acc, xent_v = torch.stack([total.detach().float().reshape(()), correct.float().mean(),

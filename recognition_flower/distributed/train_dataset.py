@@ -75,6 +75,13 @@ flags.DEFINE_float("eval_poll_seconds", 0.5, "evaluator: pause between looks at 
 flags.DEFINE_float("eval_timeout", 120.0, "evaluator: stop when no new checkpoint appeared for this many seconds.")
 flags.DEFINE_float("collective_timeout", 600.0, "Collective modes: seconds a rank waits inside a collective before the job "
                    "aborts (a lost rank must end the job so that a restart with --resume can take over).")
+flags.DEFINE_string("optimizer", "adam", "adam (the reference) | momentum")
+flags.DEFINE_float("momentum", 0.9, "momentum optimizer: heavy-ball coefficient.")
+flags.DEFINE_float("weight_decay", 0.0, "momentum optimizer: L2 weight decay on convolution / dense kernels.")
+flags.DEFINE_integer("lr_decay_steps", 0, "Exponential learning-rate decay period in global steps (0 = constant rate, as "
+                     "the reference's distributed script; its single-process script uses 200).")
+flags.DEFINE_float("lr_decay_rate", 0.95, "Exponential learning-rate decay factor per lr_decay_steps.")
+flags.DEFINE_string("grad_dtype", "fp32", "Collective modes: dtype of the gradient buckets on the wire -- fp32 | bf16.")
 flags.DEFINE_float("worker_timeout", 30.0, "Seconds of silence after which a worker no longer counts for the staleness bound.")
 
 FLAGS = flags.FLAGS
@@ -159,13 +166,25 @@ def run_worker(spec):
         {"dropout_rate": FLAGS.head_dropout_rate} if model_name == "flower_cnn" else {})
     model = build_model(model_name, num_classes=n_classes, device=device, **kw)
 
+    opt_name = FLAGS.optimizer.lower()
+    opt_kwargs = {"momentum": FLAGS.momentum, "weight_decay": FLAGS.weight_decay} if opt_name == "momentum" else {}
+    lr = params["learning_rate"]
+    if FLAGS.lr_decay_steps > 0:
+        from distributed_tensorflow_amd.optim.schedules import exponential_decay
+
+        lr_schedule = exponential_decay(lr, FLAGS.lr_decay_steps, FLAGS.lr_decay_rate)
+    else:
+        lr_schedule = lr
     if FLAGS.mode == "async_ps" and spec.ps_hosts:
         from distributed_tensorflow_amd.parallel.ps import PSWorkerEngine
 
+        if FLAGS.lr_decay_steps > 0:
+            raise ValueError("--lr_decay_steps needs a collective mode: the ps tasks apply a constant rate")
         ps_addr = [spec.address("ps", i) for i in range(len(spec.ps_hosts))]
         ps_addr = [("127.0.0.1" if h == "localhost" else h, p) for h, p in ps_addr]
-        engine = PSWorkerEngine(model, ps_addr, task_index, is_chief, optimizer="adam",
-                                lr=params["learning_rate"])
+        # a resuming chief restores the checkpoint first and initialises the ps tasks from it
+        engine = PSWorkerEngine(model, ps_addr, task_index, is_chief, optimizer=opt_name, lr=lr, opt_kwargs=opt_kwargs,
+                                defer_init=FLAGS.resume and is_chief)
     else:
         import torch.distributed as dist
         from distributed_tensorflow_amd.parallel.engine import DataParallelEngine
@@ -178,9 +197,10 @@ def run_worker(spec):
             dist.init_process_group("nccl" if device.type == "cuda" else "gloo", rank=task_index, world_size=world,
                                     timeout=datetime.timedelta(seconds=FLAGS.collective_timeout))
         mode = "sync_dp" if FLAGS.mode == "async_ps" else FLAGS.mode
-        engine = DataParallelEngine(model, mode=mode, optimizer="adam", lr=params["learning_rate"],
+        grad_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[FLAGS.grad_dtype]
+        engine = DataParallelEngine(model, mode=mode, optimizer=opt_name, lr=lr_schedule, opt_kwargs=opt_kwargs,
                                     bucket_mb=FLAGS.bucket_mb, staleness=max(FLAGS.staleness, 0),
-                                    p2p_max_bytes=FLAGS.p2p_small_kb * 1024)
+                                    p2p_max_bytes=FLAGS.p2p_small_kb * 1024, grad_dtype=grad_dtype)
     saver = Saver(model, engine)
     start_step = 0
     # async_ps: the chief restores and uploads to the ps tasks; collective modes: every rank loads the file
@@ -190,6 +210,9 @@ def run_worker(spec):
         if restored is not None:
             start_step = restored
             print("resumed from global step", restored)
+    if hasattr(engine, "initialize"):
+        engine.initialize()  # (deferred on a resuming chief; a no-op otherwise)
+        start_step = max(start_step, int(engine.global_step))
 
     hooks = [StopAtStepHook(params["train_steps"]),
              CheckpointSaverHook(FLAGS.checkpoint_dir, FLAGS.save_steps, saver),

@@ -147,6 +147,46 @@ def test_softmax_xent(B, n, ld):
     torch.testing.assert_close(m.cpu()[0], loss.mean().detach(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(32, 1024), (5, 8), (1024, 1024), (3, 7, 64)])
+def test_activity_l2_forward_backward(shape):
+    """Fused regulariser of the head's hidden layer: coef/2 * sum(h^2) and dh = dh_in + coef * g * h."""
+    from distributed_tensorflow_amd.ops import functional as F
+
+    h = _rand(*shape, seed=21)
+    dh_in = _rand(*shape, seed=22)
+    coef = 5e-4
+    hf = h.float().requires_grad_(True)
+    reg_ref = 0.5 * coef * (hf ** 2).sum()
+    (0.7 * reg_ref + (hf * dh_in.float()).sum()).backward()
+    hg = h.cuda().requires_grad_(True)
+    out, reg = F.activity_l2(hg, coef)
+    assert out.data_ptr() == hg.data_ptr()
+    torch.testing.assert_close(reg.cpu(), reg_ref.detach(), rtol=1e-4, atol=1e-6)
+    (0.7 * reg + (out.float() * dh_in.cuda().float()).sum()).backward()
+    torch.testing.assert_close(hg.grad.float().cpu(), hf.grad, rtol=1e-2, atol=1e-3)
+    # regulariser only (no gradient from above)
+    hg2 = h.cuda().requires_grad_(True)
+    F.activity_l2(hg2, coef)[1].backward()
+    torch.testing.assert_close(hg2.grad.float().cpu(), coef * h.float(), rtol=1e-2, atol=1e-6)
+
+
+def test_softmax_xent_activity_term_is_a_batch_sum():
+    from distributed_tensorflow_amd.ops import functional as F
+
+    B, n = 32, 5
+    logits = _rand(B, 8, seed=5, scale=2.0)
+    labels = torch.randint(0, n, (B,), dtype=torch.int32)
+    lf = logits.float()[:, :n]
+    want = torch.nn.functional.cross_entropy(lf, labels.long()) + 5e-4 * 0.5 * (lf ** 2).sum()
+    lg = logits.cuda().requires_grad_(True)
+    loss, _, _, _ = F.softmax_xent(lg, labels.cuda(), n, act_l2=5e-4)
+    torch.testing.assert_close(loss.cpu(), want, rtol=1e-3, atol=1e-4)
+    loss.backward()
+    lfr = logits.float().requires_grad_(True)
+    (torch.nn.functional.cross_entropy(lfr[:, :n], labels.long()) + 5e-4 * 0.5 * (lfr[:, :n] ** 2).sum()).backward()
+    torch.testing.assert_close(lg.grad.float().cpu(), lfr.grad, rtol=2e-2, atol=2e-4)
+
+
 @pytest.mark.parametrize("gdtype", [torch.float32, torch.bfloat16])
 def test_adam_matches_tf1_formula(gdtype):
     n = 100003

@@ -1,4 +1,4 @@
-"""Collective data-parallel engine on CPU tensors with gloo (world size 2).
+"""Collective data-parallel engine on CPU tensors with gloo (world sizes 2, 4 and 8).
 
 The same engine code runs over RCCL on GPUs; these tests pin down the
 arithmetic: gradient averaging, equivalence of the all-reduce and the
@@ -73,15 +73,15 @@ def _worker(rank, world, port, mode, opt, steps, staleness, out_dir):
         dist.destroy_process_group()
 
 
-def _spawn(mode, opt, steps, staleness, out_dir):
-    mp.spawn(_worker, args=(2, _free_port(), mode, opt, steps, staleness, out_dir), nprocs=2, join=True)
-    return [torch.load(os.path.join(out_dir, "%s_%s_r%d.pt" % (mode, opt, r))) for r in range(2)]
+def _spawn(mode, opt, steps, staleness, out_dir, world=2):
+    mp.spawn(_worker, args=(world, _free_port(), mode, opt, steps, staleness, out_dir), nprocs=world, join=True)
+    return [torch.load(os.path.join(out_dir, "%s_%s_r%d.pt" % (mode, opt, r))) for r in range(world)]
 
 
-def _reference(opt, steps, delay=0):
+def _reference(opt, steps, delay=0, world=2):
     """Single process: per-replica gradients computed separately (each replica has its own
     batch-norm statistics), averaged, applied -- optionally ``delay`` steps late."""
-    models = [_model(), _model()]
+    models = [_model() for _ in range(world)]
     okw = {"momentum": 0.9, "weight_decay": 1e-3} if opt == "momentum" else {}
     engs = [DataParallelEngine(m, mode="sync_dp", optimizer=opt, lr=0.05 if opt == "momentum" else 1e-2,
                                opt_kwargs=okw, bucket_mb=0.02) for m in models]
@@ -93,18 +93,18 @@ def _reference(opt, steps, delay=0):
             _loss(m, *_batch(r, t)).backward()
             e.flat.collect_autograd_grads()
             grads.append([g.grad.clone() for g in e.flat.groups])
-        pending.append([(a + b) for a, b in zip(*grads)])
+        pending.append([sum(gs) for gs in zip(*grads)])
         if len(pending) > delay:
             avg = pending.pop(0)
             for e in engs:
                 for g, s in zip(e.flat.groups, avg):
                     g.grad.copy_(s)
-                e.optimizer.step(grad_scale=0.5)
+                e.optimizer.step(grad_scale=1.0 / world)
     for avg in pending:
         for e in engs:
             for g, s in zip(e.flat.groups, avg):
                 g.grad.copy_(s)
-            e.optimizer.step(grad_scale=0.5)
+            e.optimizer.step(grad_scale=1.0 / world)
     return torch.cat([g.master[s.offset:s.offset + s.numel] for g in engs[0].flat.groups for s in g.segments])
 
 
@@ -133,6 +133,81 @@ def test_async_ssp_applies_gradients_exactly_s_steps_late(tmp_path):
     torch.testing.assert_close(s2[0]["flat"], s2[1]["flat"], rtol=0, atol=0)
     torch.testing.assert_close(s2[0]["flat"], _reference("momentum", 4, delay=2), rtol=1e-5, atol=1e-6)
     assert not torch.equal(s2[0]["flat"], sync[0]["flat"])
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_all_modes_at_larger_world_sizes(tmp_path, world):
+    """The three collective modes at 4 and 8 ranks (the size of an MI355X node): replicas identical, the
+    all-reduce result equals manual averaging over ``world`` replicas, sharded ownership is bitwise equal to it
+    (1/world of every bucket per rank, stepped, not just laid out), delayed apply equals the delayed reference."""
+    sync = _spawn("sync_dp", "momentum", 3, 0, str(tmp_path), world)
+    for r in range(1, world):
+        torch.testing.assert_close(sync[r]["flat"], sync[0]["flat"], rtol=0, atol=0)
+    # gloo reduces in a ring / tree order of its own: equal to the sequential sum up to fp32 rounding
+    torch.testing.assert_close(sync[0]["flat"], _reference("momentum", 3, world=world), rtol=2e-5, atol=2e-6)
+    shard = _spawn("sharded_ps", "momentum", 3, 0, str(tmp_path), world)
+    for r in range(world):
+        torch.testing.assert_close(shard[r]["compute"], shard[0]["compute"], rtol=0, atol=0)
+    # same arithmetic, reduction order of reduce-scatter vs all-reduce may differ in gloo beyond two ranks
+    torch.testing.assert_close(shard[0]["flat"], sync[0]["flat"], rtol=2e-5, atol=2e-6)
+    ssp = _spawn("async_ssp", "momentum", 4, 1, str(tmp_path), world)
+    for r in range(1, world):
+        torch.testing.assert_close(ssp[r]["flat"], ssp[0]["flat"], rtol=0, atol=0)
+    torch.testing.assert_close(ssp[0]["flat"], _reference("momentum", 4, delay=1, world=world), rtol=2e-5, atol=2e-6)
+
+
+def test_async_ssp_drain_then_continue_applies_every_gradient_once():
+    """A drain in the middle of a run (what a periodic checkpoint does) applies the in-flight gradients early;
+    the following steps must not apply them a second time."""
+    steps, s = 6, 2
+    model = _model()
+    eng = DataParallelEngine(model, mode="async_ssp", optimizer="momentum", lr=0.05, staleness=s, bucket_mb=0.02)
+    applied = []
+    for t in range(steps):
+        eng.begin_step()
+        _loss(model, *_batch(0, t)).backward()
+        eng.finish_step()
+        if t in (2, 3):
+            eng.drain()
+            assert eng.optimizer.step_count == t + 1  # everything up to this step has landed, once
+        applied.append(eng.optimizer.step_count)
+    eng.drain()
+    assert eng.optimizer.step_count == steps
+    # between drains the schedule is the delayed one again: step 4 applies nothing new (its own gradient waits),
+    # step 5 still nothing (s = 2), the final drain lands both
+    assert applied == [0, 0, 3, 4, 4, 4]
+
+
+def _ssp_ckpt_worker(rank, world, port, out_dir):
+    from distributed_tensorflow_amd.io.saver import Saver
+    from distributed_tensorflow_amd.train.session import CheckpointSaverHook, TrainingSession
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _model()
+        eng = DataParallelEngine(model, mode="async_ssp", optimizer="momentum", lr=0.05, staleness=1, bucket_mb=0.02)
+        saver = Saver(model, eng)
+        hooks = [CheckpointSaverHook(os.path.join(out_dir, "ckpt"), 2, saver, background=False)]
+        sess = TrainingSession(model, eng, num_classes=5, hooks=hooks, is_chief=rank == 0)
+        with sess:
+            for t in range(5):
+                sess.run_step(*_batch(rank, t))
+        eng.drain()
+        flat = torch.cat([g.master[s.offset:s.offset + s.numel].clone() for g in eng.flat.groups for s in g.segments])
+        torch.save({"flat": flat, "steps": eng.optimizer.step_count}, os.path.join(out_dir, "ssp_ckpt_r%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_async_ssp_periodic_checkpoints_keep_replicas_identical(tmp_path):
+    """Checkpoints every 2 steps (the reference's cadence) drain the in-flight gradients; that must happen on
+    every rank at the same step, not on the chief alone."""
+    mp.spawn(_ssp_ckpt_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = [torch.load(os.path.join(str(tmp_path), "ssp_ckpt_r%d.pt" % r)) for r in range(2)]
+    assert a["steps"] == b["steps"] == 5
+    torch.testing.assert_close(a["flat"], b["flat"], rtol=0, atol=0)
+    assert os.path.exists(os.path.join(str(tmp_path), "ckpt", "checkpoint"))
 
 
 def test_async_ssp_first_s_steps_leave_parameters_untouched(monkeypatch):

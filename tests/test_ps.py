@@ -215,3 +215,113 @@ def test_debug_mode_rejects_a_push_with_a_wrong_clock(servers):
         _step(model, eng, 1)
     assert any("pushed clock" in v for v in ps.violations)
     eng.close()
+
+
+def _params(model):
+    return torch.cat([p.detach().float().reshape(-1).clone() for p in model.parameters()])
+
+
+def test_resume_restores_variables_slots_and_global_step(servers, tmp_path):
+    """A run interrupted after 3 steps and resumed from its checkpoint (new ps task, new workers) ends where the
+    uninterrupted run ends: Adam moments, beta powers (step count) and the global step travel to the ps."""
+    (ps, addr), = servers(1)
+    model = _model(1)
+    eng = PSWorkerEngine(model, [addr], 0, True, optimizer="adam", lr=1e-2)
+    for t in range(3):
+        _step(model, eng, t)
+    saver = Saver(model, eng)
+    prefix = saver.save(str(tmp_path), 3)
+    assert prefix.endswith("model.ckpt-3")
+    for t in range(3, 5):
+        gs, _ = _step(model, eng, t)
+    assert gs == 5
+    eng.pull()
+    want = _params(model)
+    eng.close()
+
+    (ps2, addr2), = servers(1)
+    chief_model = _model(9)  # a fresh process would start from some other initial values
+    chief = PSWorkerEngine(chief_model, [addr2], 0, True, optimizer="adam", lr=1e-2, defer_init=True)
+    assert not ps2.initialized
+    # a second worker arriving early waits for the chief's (restored) initialisation
+    joined = {}
+
+    def join():
+        m = _model(5)
+        joined["eng"] = PSWorkerEngine(m, [addr2], 1, False, optimizer="adam", lr=1e-2)
+        joined["model"] = m
+
+    th = threading.Thread(target=join)
+    th.start()
+    time.sleep(0.3)
+    assert "eng" not in joined
+    assert Saver(chief_model, chief).restore_latest(str(tmp_path)) == 3
+    chief.initialize()
+    th.join(timeout=20)
+    assert ps2.global_step == 3 and ps2.optimizer.step_count == 3
+    assert joined["eng"].global_step == 3
+    torch.testing.assert_close(_params(joined["model"]), _params(chief_model), rtol=0, atol=0)
+    slots = ps2.optimizer.slots()
+    assert all(float(v.abs().sum()) > 0 for v in slots.values())  # the moments came along
+    for t in range(3, 5):
+        gs, _ = _step(chief_model, chief, t)
+    assert gs == 5
+    chief.pull()
+    torch.testing.assert_close(_params(chief_model), want, rtol=1e-6, atol=1e-7)
+    chief.close()
+    joined["eng"].close()
+
+
+def test_set_state_after_init_restores_slots_too(servers, tmp_path):
+    """Restore into an already initialised cluster (``load_master`` / ``load_full_slots`` over OP_SET_STATE)."""
+    (ps, addr), = servers(1)
+    model = _model(1)
+    eng = PSWorkerEngine(model, [addr], 0, True, optimizer="adam", lr=1e-2)
+    for t in range(2):
+        _step(model, eng, t)
+    saver = Saver(model, eng)
+    saver.save(str(tmp_path), 2)
+    m_before = {k: v.clone() for k, v in ps.optimizer.slots().items()}
+    for t in range(2, 4):
+        _step(model, eng, t)
+    assert saver.restore_latest(str(tmp_path)) == 2
+    assert ps.global_step == 2 and ps.optimizer.step_count == 2
+    for k, v in ps.optimizer.slots().items():
+        torch.testing.assert_close(v, m_before[k], rtol=0, atol=0)
+    eng.close()
+
+
+def test_periodic_hooks_fire_when_the_chief_only_sees_odd_global_steps(servers, tmp_path):
+    """Two asynchronous workers alternate; the chief's updates produce global steps 1, 3, 5, ...  Hooks that fire
+    'every 2 global steps' must still fire (when a multiple of 2 has been passed), and the checkpoint carries
+    the global step of the state fetched from the ps."""
+    from distributed_tensorflow_amd.io.events import read_events
+    from distributed_tensorflow_amd.train.session import CheckpointSaverHook, SummarySaverHook, TrainingSession
+
+    (ps, addr), = servers(1)
+    chief_model, other_model = _model(1), _model(1)
+    chief = PSWorkerEngine(chief_model, [addr], 0, True, lr=1e-2)
+    other = PSWorkerEngine(other_model, [addr], 1, False, lr=1e-2)
+    saver = Saver(chief_model, chief)
+    ckpt_dir, ev_dir = str(tmp_path / "ckpt"), str(tmp_path / "events")
+    hooks = [CheckpointSaverHook(ckpt_dir, 2, saver, save_at_end=False, background=False),
+             SummarySaverHook(2, ev_dir, histogram=False)]
+    sess = TrainingSession(chief_model, chief, num_classes=5, hooks=hooks, is_chief=True)
+    seen = []
+    with sess:
+        for t in range(3):
+            r = sess.run_step(*_batch(t))
+            seen.append(r.global_step)
+            _step(other_model, other, 100 + t)
+    assert seen == [1, 3, 5]
+    import glob
+    import os
+
+    names = sorted(f for f in os.listdir(ckpt_dir) if f.endswith(".index"))
+    assert names == ["model.ckpt-3.index", "model.ckpt-5.index"], names
+    assert bundle.latest_checkpoint(ckpt_dir).endswith("model.ckpt-5")
+    steps = sorted({e["step"] for f in glob.glob(os.path.join(ev_dir, "events.out.tfevents.*"))
+                    for e in read_events(f) if e["scalars"]})
+    assert steps == [3, 5], steps
+    chief.close()
+    other.close()
