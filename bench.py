@@ -57,7 +57,9 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
             # 0.02 and 0.002 oscillate upwards, 0.0005 descends.
             lr = lr / 40
     engine = DataParallelEngine(model, mode=mode, optimizer=opt, lr=lr, opt_kwargs=okw,
-                                bucket_mb=args.bucket_mb, staleness=args.staleness, p2p_max_bytes=args.p2p_kb * 1024)
+                                bucket_mb=args.bucket_mb, staleness=args.staleness, p2p_max_bytes=args.p2p_kb * 1024,
+                                grad_dtype={"fp32": torch.float32, "bf16": torch.bfloat16}[args.grad_dtype])
+    engine.measure_comm = not args.hip_graph  # (events cannot be timed inside a captured graph)
 
     # synthetic batch generated on the device (a 2048 x 224 x 224 host tensor per rank would cost seconds and GBs)
     g = torch.Generator(device=device).manual_seed(1000 + rank)
@@ -99,6 +101,7 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
     for _ in range(args.warmup):
         step()
     sync()
+    engine.reset_comm_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -111,7 +114,7 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
     ips = batch * world * args.steps / dt
     return {"value": round(ips, 2), "ms_per_step": round(dt / args.steps * 1e3, 3), "final_loss": round(float(loss.item()), 4),
             "per_gpu_batch": batch, "global_batch": batch * world, "optimizer": opt,
-            "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2**30, 2)}
+            "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2**30, 2), "comm": engine.comm_stats()}
 
 
 def main():
@@ -124,6 +127,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default depends on the model)")
     ap.add_argument("--bucket_mb", type=float, default=32.0)
     ap.add_argument("--staleness", type=int, default=1)
+    ap.add_argument("--grad_dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="dtype of the gradient buckets (what the collectives move): bf16 halves the bytes on xGMI")
     ap.add_argument("--p2p_kb", type=int, default=0,
                     help="gradient buckets up to this many KiB use the one-shot xGMI mailbox all-reduce (sync_dp)")
     ap.add_argument("--trunk_bn", default="batch", choices=["batch", "moving"],
@@ -196,6 +201,10 @@ def main():
                        "image_size": IMAGE_SIZE[args.model], "num_classes": 5, "parallelism": "dp%d" % world,
                        "mode": args.mode, "optimizer": head["optimizer"], "hip_graph": bool(args.hip_graph)},
             "peak_mem_gb": head["peak_mem_gb"],
+            # communication of the headline run: RCCL world, gradient buckets (count / bytes each / dtype) and the
+            # time per step the compute stream spent waiting for collectives that backward did not hide
+            "rccl_world": world if dist.is_initialized() else 0,
+            "comm": head["comm"],
             "also": also,
         }), flush=True)
     if dist.is_initialized():

@@ -643,11 +643,15 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   size_t lds = MAX_TAPS * 4 + (size_t)((NST * STAGE > EP) ? NST * STAGE : EP);
   unsigned mtiles = (a.M + BM - 1) / BM, ntiles = (a.Cout + BN - 1) / BN;
   unsigned mgroups = (mtiles + WG - 1) / WG;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
+  // the dynamic-LDS limit is a per-device function attribute: remember it per device, not per process
+  static bool attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev = (dev >= 0 && dev < 64) ? dev : 0;
+  if (!attr_set[dev] && lds > 48 * 1024) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, EPI, NST, WG>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, EPI, NST, WG>), dim3(mgroups * ntiles), dim3(256 * WG), lds,
                      stream, a);

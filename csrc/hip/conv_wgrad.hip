@@ -315,10 +315,14 @@ template <int BMW, int BNW, int BKP>
 static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t stream) {
   size_t lds = MAX_TAPS * 4 + (BKP == 32 ? 3 : 2) * (size_t)BKP * (BMW * 2 + BNW * 2);
   unsigned mt = (a.Cout + BMW - 1) / BMW, nt = (a.K + BNW - 1) / BNW;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
+  // the dynamic-LDS limit is a per-device function attribute: remember it per device, not per process
+  static bool attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev = (dev >= 0 && dev < 64) ? dev : 0;
+  if (!attr_set[dev] && lds > 48 * 1024) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, BKP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   unsigned split_groups = (splits + 7) / 8;
   hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, BKP>), dim3(mt * nt * split_groups * 8), dim3(256), lds, stream, a);

@@ -75,6 +75,11 @@ class DataParallelEngine:
         self.flat.on_bucket_ready = self._on_bucket_ready
         self._handles: List = []
         self._step = 0
+        # communication accounting (``measure_comm``): device events around the point where the compute stream
+        # waits for the step's collectives; their distance is the communication time NOT hidden behind backward
+        self.measure_comm = False
+        self._comm_events: List = []
+        self._comm_calls = 0
         opt_kwargs = dict(opt_kwargs or {})
         if mode == "sharded_ps":
             self._build_shards()
@@ -206,6 +211,40 @@ class DataParallelEngine:
         self.optimizer.advance()
         self._step += 1
 
+    def _wait_handles(self, handles) -> None:
+        """Make the current stream wait for the collectives of this step."""
+        if not handles:
+            return
+        timed = self.measure_comm and self.flat.device.type == "cuda"
+        if timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        for h in handles:
+            h.wait()
+        if timed:
+            b.record()
+            self._comm_events.append((a, b))
+        self._comm_calls += len(handles)
+
+    def comm_stats(self) -> dict:
+        """Bucket layout and, after a ``measure_comm`` run, the exposed collective wait per step (ms).  Call after a
+        device synchronisation."""
+        buckets = [b for g in self.flat.groups for b in g.buckets]
+        esz = self.flat.groups[0].grad.element_size() if self.flat.groups else 4
+        out = {"collective": bool(self.collective), "world": self.world, "mode": self.mode,
+               "grad_dtype": str(self.flat.groups[0].grad.dtype).replace("torch.", "") if self.flat.groups else None,
+               "buckets": len(buckets), "bucket_bytes": [int(b.numel * esz) for b in buckets],
+               "gradient_bytes": int(sum(b.numel for b in buckets) * esz),
+               "collectives_waited": self._comm_calls}
+        if self._comm_events:
+            ms = [a.elapsed_time(b) for a, b in self._comm_events]
+            out["exposed_wait_ms_per_step"] = round(sum(ms) / len(ms), 4)
+            out["exposed_wait_ms_max"] = round(max(ms), 4)
+        return out
+
+    def reset_comm_stats(self) -> None:
+        self._comm_events, self._comm_calls = [], 0
+
     def _opt_step(self, scale: float, prepared: bool) -> None:
         if not prepared:
             self.optimizer.prepare(scale)
@@ -226,8 +265,7 @@ class DataParallelEngine:
             if not self.collective:
                 for g in self.flat.groups:
                     self._grad_shard[g.name].copy_(g.grad)
-            for h in self._handles:
-                h.wait()
+            self._wait_handles(self._handles)
             self._opt_step(scale, prepared)
             self._gather_params()
         elif self.mode == "async_ssp" and self.staleness > 0:
@@ -242,16 +280,14 @@ class DataParallelEngine:
                 if self._debug_staleness and self._ring_version[apply_slot] != self._step - s:
                     raise AssertionError("staleness violation: applying the gradient of step %d at step %d (bound %d)"
                                          % (self._ring_version[apply_slot], self._step, s))
-                for h in self._ring_handles[apply_slot]:
-                    h.wait()
+                self._wait_handles(self._ring_handles[apply_slot])
                 self._ring_handles[apply_slot] = []
                 for r in self.optimizer.regions:
                     r.g = self._ring[apply_slot][r.name]
                 self.optimizer.step(grad_scale=scale)
                 self._applied_through = self._step - s + 1
         else:
-            for h in self._handles:
-                h.wait()
+            self._wait_handles(self._handles)
             self._opt_step(scale, prepared)
         self._handles = []
         if not prepared:
@@ -286,8 +322,7 @@ class DataParallelEngine:
                     handles.append(dist.all_gather_into_tensor(dst, src, group=self.pg, async_op=True))
                 else:
                     dst.copy_(src)
-        for h in handles:
-            h.wait()
+        self._wait_handles(handles)
 
     # ------------------------------------------------------------------ export
     def full_master(self) -> Dict[str, torch.Tensor]:

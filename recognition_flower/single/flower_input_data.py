@@ -18,8 +18,8 @@ import torch  # noqa: E402
 from distributed_tensorflow_amd.data import jpeg as _jpeg  # noqa: E402
 from distributed_tensorflow_amd.data.flowers import (get_image_path_and_class, listdir_without_hidden,  # noqa: E402,F401
                                                      prepare_batch, prepare_image, read_image, sample_batch)
-from distributed_tensorflow_amd.data.preprocess import (NORM_INCEPTION, make_descs, random_crop_spec,  # noqa: E402
-                                                        resize_on_device)
+from distributed_tensorflow_amd.data.preprocess import (NORM_INCEPTION, NORM_UNIT, full_crop, make_descs,  # noqa: E402
+                                                        random_crop_spec, resize_on_device, resize_reference)
 
 
 def prepare_batch_on_device(flower_paths_and_classes, batch_size, device, image_size=299, max_zoom=0.2, np_rng=None):
@@ -38,3 +38,30 @@ def prepare_batch_on_device(flower_paths_and_classes, batch_size, device, image_
     X = resize_on_device(packed, descs, len(batch), (image_size, image_size), "bilinear", False, NORM_INCEPTION)
     y = torch.tensor([c for _, c in batch], dtype=torch.int32, device=device)
     return X, y
+
+
+def evaluation_batches(flower_paths_and_classes, batch_size, device, image_size=299):
+    """Every item once, in order, WITHOUT augmentation: the whole image resized (bilinear) to the network size,
+    [-1, 1].  Yields ``(X, y)`` like the training batches (device: bf16 NHWC8; CPU: fp32 NHWC8).  This is the
+    pass over the held-out 20 % that the reference splits off and never runs
+    (recognition_flower/single/flower_train.py:101-106)."""
+    device = torch.device(device)
+    items = list(flower_paths_and_classes)
+    for i in range(0, len(items), batch_size):
+        batch = items[i:i + batch_size]
+        y = torch.tensor([c for _, c in batch], dtype=torch.int32, device=device)
+        if device.type == "cuda":
+            jpegs = []
+            for path, _ in batch:
+                with open(path, "rb") as f:
+                    jpegs.append(f.read())
+            packed, shapes, offs = _jpeg.decode_batch_to_device(jpegs, device)
+            descs = torch.from_numpy(make_descs(shapes, offs, [full_crop(h, w) for h, w, _ in shapes])).to(device)
+            X = resize_on_device(packed, descs, len(batch), (image_size, image_size), "bilinear", False, NORM_INCEPTION)
+        else:
+            Xn = np.zeros((len(batch), image_size, image_size, 8), dtype=np.float32)
+            for k, (path, _) in enumerate(batch):
+                Xn[k, :, :, :3] = 2.0 * resize_reference(read_image(path), (image_size, image_size), "bilinear", None,
+                                                         norm=NORM_UNIT) - 1.0
+            X = torch.from_numpy(Xn)
+        yield X, y

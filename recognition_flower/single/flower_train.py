@@ -20,7 +20,8 @@ and ``predict_images`` signatures under ``<output_dir>/<model_version>``.
 Deliberate differences: accuracy is taken from the training forward pass (the
 reference runs a second full forward per step for it), summaries are indexed by
 global step (the reference uses the epoch index), the held-out 20 % is actually
-evaluated at the end, and on a GPU the JPEG decode / augmentation / resize run
+evaluated at the end (every image once, un-augmented; ``accuracy`` / ``loss``
+written under ``<summaries_dir><model_version>/eval``), and on a GPU the JPEG decode / augmentation / resize run
 on the device.  ``--model=flower_cnn`` trains the small end-to-end CNN instead
 (the default on a machine without a GPU).
 """
@@ -148,10 +149,20 @@ def main(argv):
         if prefetcher is not None:
             prefetcher.close()
         if test:
-            bs = min(len(test), batch_size)
-            X, y = next_batch(test, bs)
-            ev = sess.evaluate(X, y)
-            print("held-out batch: accuracy %.4f loss %.4f" % (ev["accuracy"], ev["loss"]))
+            # the whole held-out split, each image once, no augmentation; example-weighted means
+            n = 0
+            acc_sum = loss_sum = 0.0
+            for X, y in flower_input_data.evaluation_batches(test, batch_size, device, FLAGS.image_size):
+                ev = sess.evaluate(X, y)
+                k = int(y.shape[0])
+                acc_sum, loss_sum, n = acc_sum + ev["accuracy"] * k, loss_sum + ev["loss"] * k, n + k
+            held_out = {"accuracy": acc_sum / n, "loss": loss_sum / n}
+            print("held-out set (%d images): accuracy %.4f loss %.4f" % (n, held_out["accuracy"], held_out["loss"]))
+            from distributed_tensorflow_amd.io.events import EventWriter
+
+            ew = EventWriter(os.path.join(FLAGS.summaries_dir + str(FLAGS.model_version), "eval"))
+            ew.add_summary(sess.global_step, held_out, {})
+            ew.close()
         if FLAGS.checkpoint_dir:
             print("checkpoint:", sess.save_checkpoint(saver, FLAGS.checkpoint_dir, sess.global_step))
     print("trained %d steps in %.1fs (%.1f images/sec)" % (sess.global_step - global_step, time.time() - t0,

@@ -12,8 +12,11 @@ from distributed_tensorflow_amd.data import flowers, jpeg, preprocess
 from distributed_tensorflow_amd.data.records import RecordInput
 from distributed_tensorflow_amd.io import tfrecord
 
-REF_DATA = "/root/reference/recognition_flower/flower_photos_labeled"
-needs_ref_data = pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="reference flower photos not mounted")
+# the bundled sample dataset (drawn by tools/make_flower_fixture.py; same class / file counts and size range as
+# the photographs the reference ships in its tree)
+REF_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "recognition_flower",
+                        "flower_photos_labeled")
+needs_ref_data = pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="bundled sample dataset missing (run tools/make_flower_fixture.py)")
 
 
 def _make_dataset(root, n_per_class=4, seed=0):

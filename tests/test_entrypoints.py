@@ -36,9 +36,15 @@ def test_single_trainer_trains_exports_and_serves(tmp_path):
               "--checkpoint_dir=%s/ckpt" % out, "--model_version=3", "--profile_dir=%s/prof" % out], SINGLE)
     assert r.returncode == 0, r.stdout[-3000:]
     assert glob.glob(str(out / "prof" / "trace_steps_*.json"))  # torch.profiler window
-    losses = [float(m) for m in re.findall(r"loss (\d+\.\d+)", r.stdout)]
+    losses = [float(m) for m in re.findall(r"step \d+: .* loss (\d+\.\d+)", r.stdout)]
     assert len(losses) >= 12 and np.mean(losses[-3:]) < np.mean(losses[:3])  # loss decreases
     assert "Done exporting!" in r.stdout
+    # the whole held-out 20 % (24 images -> 5) is evaluated, un-augmented, and written as eval summaries
+    assert re.search(r"held-out set \(5 images\): accuracy \d\.\d+ loss \d+\.\d+", r.stdout), r.stdout[-1500:]
+    ev_eval = glob.glob(str(out / "events" / "3" / "eval" / "events.out.tfevents.*"))
+    assert len(ev_eval) == 1
+    ee = [e for e in events.read_events(ev_eval[0]) if e["scalars"]]
+    assert len(ee) == 1 and {"accuracy", "loss"} <= set(ee[0]["scalars"]) and ee[0]["step"] == len(losses)
     # summaries: scalars + logits histogram, indexed by global step
     ev_files = glob.glob(str(out / "events" / "3" / "train" / "events.out.tfevents.*"))
     assert len(ev_files) == 1
@@ -72,6 +78,23 @@ def test_single_trainer_trains_exports_and_serves(tmp_path):
                "--summaries_dir=%s/events2/" % out], SINGLE)
     assert r2.returncode == 0 and "restored" in r2.stdout, r2.stdout[-2000:]
     assert re.search(r"step %d:" % (len(losses) + 1), r2.stdout)  # global step continues
+
+
+def test_default_dataset_path_works_from_a_clean_checkout(tmp_path):
+    """``--dataset_path`` defaults to ``../flower_photos_labeled`` relative to the script directory, as in the
+    reference (recognition_flower/single/flower_train.py:22-23, recognition_flower/distributed/prepare.py:10-11);
+    the repository ships a drawn stand-in for the reference's 107 sample photographs there."""
+    out = tmp_path / "out"
+    r = _run(["flower_train.py", "--image_size=32", "--n_epochs=1", "--max_steps=2", "--batch_size=16",
+              "--output_dir=%s/models" % out, "--summaries_dir=%s/events/" % out], SINGLE)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "classes: ['daisy', 'dandelion', 'roses', 'sunflower', 'tulips'] | train 85 test 22" in r.stdout
+    assert re.search(r"held-out set \(22 images\)", r.stdout)
+    rec = str(tmp_path / "train_v1.tfrecord")
+    r = _run(["prepare.py", "--tfrecords_path=" + rec], DIST)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert json.load(open(rec + ".labels.json"))["classes"] == ["daisy", "dandelion", "roses", "sunflower", "tulips"]
+    assert 30e6 < os.path.getsize(rec) < 45e6  # raw pixels of the 107 images: the reference's "train_v1~38M"
 
 
 def test_distributed_ps_workers_checkpoint_and_export(tmp_path):

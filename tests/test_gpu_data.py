@@ -12,7 +12,10 @@ from distributed_tensorflow_amd.data.records import RecordInput
 from distributed_tensorflow_amd.io import tfrecord
 
 pytestmark = pytest.mark.gpu
-REF_DATA = "/root/reference/recognition_flower/flower_photos_labeled"
+# the bundled sample dataset (drawn by tools/make_flower_fixture.py; same class / file counts and size range as
+# the photographs the reference ships in its tree)
+REF_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "recognition_flower",
+                        "flower_photos_labeled")
 
 
 @pytest.mark.parametrize("method", ["bilinear_legacy", "bilinear", "bicubic_legacy"])
@@ -68,7 +71,7 @@ def test_jpeg_device_decode_matches_numpy_and_libjpeg():
     assert np.abs(got0 - pil).max() <= 3
 
 
-@pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="reference flower photos not mounted")
+@pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="bundled sample dataset missing (run tools/make_flower_fixture.py)")
 def test_reference_photos_decode_augment_resize_on_device():
     files = sorted(glob.glob(os.path.join(REF_DATA, "*", "*.jpg")))[:16]
     jpegs = [open(f, "rb").read() for f in files]

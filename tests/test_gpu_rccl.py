@@ -29,6 +29,8 @@ def _port():
     ["--mode", "sync_dp", "--p2p_kb", "4096", "--bucket_mb", "1"],
     ["--mode", "sync_dp", "--hip_graph", "1"],
     ["--mode", "sharded_ps", "--hip_graph", "1"],
+    ["--mode", "sync_dp", "--grad_dtype", "bf16", "--bucket_mb", "1"],
+    ["--mode", "sharded_ps", "--grad_dtype", "bf16"],
 ])
 def test_bench_under_torchrun_one_rank(extra):
     env = dict(os.environ, DTFA_FORCE_COLLECTIVES="1")
@@ -41,3 +43,13 @@ def test_bench_under_torchrun_one_rank(extra):
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["final_loss"] == out["final_loss"]  # finite
     assert out["final_loss"] < 5.0
+    # communication report: the RCCL world, the gradient buckets and (eager runs) the exposed collective wait
+    assert out["rccl_world"] == 1
+    comm = out["comm"]
+    assert comm["collective"] is True and comm["world"] == 1 and comm["mode"] == extra[1]
+    assert comm["buckets"] == len(comm["bucket_bytes"]) >= 1 and sum(comm["bucket_bytes"]) == comm["gradient_bytes"]
+    assert comm["grad_dtype"] == ("bfloat16" if "bf16" in extra else "float32")
+    if "--bucket_mb" in extra:
+        assert comm["buckets"] > 1  # (a bucket holds whole tensors, so one may exceed the nominal size)
+    if "--hip_graph" not in extra and "--p2p_kb" not in extra:
+        assert comm["collectives_waited"] >= 4 and comm["exposed_wait_ms_per_step"] >= 0.0
