@@ -16,6 +16,7 @@
 // hipGraph can be replayed with new values:  hyper[0] = lr (or lr_t), hyper[1]
 // = gradient scale.
 #include "common.h"
+#include "opt_update.h"
 
 template <typename G>
 __device__ __forceinline__ float4 load_grad4(const G* g, size_t i);
@@ -39,14 +40,10 @@ __global__ void adam_kernel(float* __restrict__ w, float* __restrict__ m, float*
     if (i + 4 <= n) {
       float4 gg = load_grad4<G>(g, i);
       float4 ww = *(float4*)(w + i), mm = *(float4*)(m + i), vv = *(float4*)(v + i);
-      float ga[4] = {gg.x * gs, gg.y * gs, gg.z * gs, gg.w * gs};
+      float ga[4] = {gg.x, gg.y, gg.z, gg.w};
       float wa[4] = {ww.x, ww.y, ww.z, ww.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ma[j] = b1 * ma[j] + (1.f - b1) * ga[j];
-        va[j] = b2 * va[j] + (1.f - b2) * ga[j] * ga[j];
-        wa[j] -= lr_t * ma[j] / (sqrtf(va[j]) + eps);
-      }
+      for (int j = 0; j < 4; ++j) adam_update(wa[j], ma[j], va[j], ga[j], gs, lr_t, b1, b2, eps);
       *(float4*)(w + i) = make_float4(wa[0], wa[1], wa[2], wa[3]);
       *(float4*)(m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
       *(float4*)(v + i) = make_float4(va[0], va[1], va[2], va[3]);
@@ -56,10 +53,8 @@ __global__ void adam_kernel(float* __restrict__ w, float* __restrict__ m, float*
       }
     } else {
       for (size_t k = i; k < n; ++k) {
-        float gk = (float)g[k] * gs;
-        float mk = b1 * m[k] + (1.f - b1) * gk;
-        float vk = b2 * v[k] + (1.f - b2) * gk * gk;
-        float wk = w[k] - lr_t * mk / (sqrtf(vk) + eps);
+        float mk = m[k], vk = v[k], wk = w[k];
+        adam_update(wk, mk, vk, (float)g[k], gs, lr_t, b1, b2, eps);
         m[k] = mk; v[k] = vk; w[k] = wk;
         if (w16) w16[k] = (bf16)wk;
       }
@@ -80,11 +75,7 @@ __global__ void momentum_kernel(float* __restrict__ w, float* __restrict__ buf, 
       float ga[4] = {gg.x, gg.y, gg.z, gg.w};
       float wa[4] = {ww.x, ww.y, ww.z, ww.w}, ba[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float gp = ga[j] * gs + wd * wa[j];
-        ba[j] = mu * ba[j] + gp;
-        wa[j] -= lr * (nesterov ? gp + mu * ba[j] : ba[j]);
-      }
+      for (int j = 0; j < 4; ++j) momentum_update(wa[j], ba[j], ga[j], gs, lr, mu, wd, nesterov);
       *(float4*)(w + i) = make_float4(wa[0], wa[1], wa[2], wa[3]);
       *(float4*)(buf + i) = make_float4(ba[0], ba[1], ba[2], ba[3]);
       if (w16) {
@@ -93,9 +84,8 @@ __global__ void momentum_kernel(float* __restrict__ w, float* __restrict__ buf, 
       }
     } else {
       for (size_t k = i; k < n; ++k) {
-        float gp = (float)g[k] * gs + wd * w[k];
-        float bk = mu * buf[k] + gp;
-        float wk = w[k] - lr * (nesterov ? gp + mu * bk : bk);
+        float bk = buf[k], wk = w[k];
+        momentum_update(wk, bk, (float)g[k], gs, lr, mu, wd, nesterov);
         buf[k] = bk; w[k] = wk;
         if (w16) w16[k] = (bf16)wk;
       }

@@ -75,6 +75,11 @@ flags.DEFINE_float("eval_poll_seconds", 0.5, "evaluator: pause between looks at 
 flags.DEFINE_float("eval_timeout", 120.0, "evaluator: stop when no new checkpoint appeared for this many seconds.")
 flags.DEFINE_float("collective_timeout", 600.0, "Collective modes: seconds a rank waits inside a collective before the job "
                    "aborts (a lost rank must end the job so that a restart with --resume can take over).")
+flags.DEFINE_string("ps_backend", "tcp", "async_ps: tcp (ps processes over TCP, CPUs or GPUs, elastic worker set) | xgmi (one node "
+                    "of GPUs: every worker GPU owns 1/N of the variables and their optimizer slots, gradients are pushed into "
+                    "the owner's memory and variables pulled from it over xGMI peer access; ps tasks have nothing to do)")
+flags.DEFINE_string("ps_apply", "auto", "ps_backend=xgmi: per_push (one optimizer step per arrived gradient, the reference's ps) | "
+                    "aggregate (staleness 0 only: one step per round on the sum of the workers' gradients) | auto")
 flags.DEFINE_string("optimizer", "adam", "adam (the reference) | momentum")
 flags.DEFINE_float("momentum", 0.9, "momentum optimizer: heavy-ball coefficient.")
 flags.DEFINE_float("weight_decay", 0.0, "momentum optimizer: L2 weight decay on convolution / dense kernels.")
@@ -127,8 +132,9 @@ def train_input_fn(tfrecords_path, params, device, rank, world):
 def run_ps(spec):
     from distributed_tensorflow_amd.parallel.ps import ParameterServer
 
-    if FLAGS.mode != "async_ps":
-        print("ps task %d: mode %s keeps parameters on the workers; nothing to serve" % (spec.task_index, FLAGS.mode))
+    if FLAGS.mode != "async_ps" or FLAGS.ps_backend == "xgmi":
+        print("ps task %d: mode %s%s keeps parameters on the workers; nothing to serve" % (
+            spec.task_index, FLAGS.mode, " (xgmi)" if FLAGS.mode == "async_ps" else ""))
         return 0
     if FLAGS.wipe_checkpoint_dir and spec.task_index == 0 and os.path.exists(FLAGS.checkpoint_dir):
         shutil.rmtree(FLAGS.checkpoint_dir)
@@ -175,7 +181,25 @@ def run_worker(spec):
         lr_schedule = exponential_decay(lr, FLAGS.lr_decay_steps, FLAGS.lr_decay_rate)
     else:
         lr_schedule = lr
-    if FLAGS.mode == "async_ps" and spec.ps_hosts:
+    xgmi = FLAGS.mode == "async_ps" and FLAGS.ps_backend == "xgmi"
+    if xgmi:
+        import datetime
+
+        import torch.distributed as dist
+        from distributed_tensorflow_amd.parallel.xps import XgmiPSEngine
+
+        if device.type != "cuda":
+            raise ValueError("--ps_backend=xgmi keeps the variables in GPU memory")
+        if world > 1 and not dist.is_initialized():
+            if tr is None:
+                os.environ.update(rendezvous_from_cluster(spec))
+            # the process group only carries the IPC handles and the chief's initial values at start-up
+            dist.init_process_group("gloo", rank=task_index, world_size=world,
+                                    timeout=datetime.timedelta(seconds=FLAGS.collective_timeout))
+        grad_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[FLAGS.grad_dtype]
+        engine = XgmiPSEngine(model, optimizer=opt_name, lr=lr_schedule, opt_kwargs=opt_kwargs, staleness=FLAGS.staleness,
+                              apply=FLAGS.ps_apply, grad_dtype=grad_dtype, timeout=FLAGS.worker_timeout)
+    elif FLAGS.mode == "async_ps" and spec.ps_hosts:
         from distributed_tensorflow_amd.parallel.ps import PSWorkerEngine
 
         if FLAGS.lr_decay_steps > 0:
@@ -204,7 +228,7 @@ def run_worker(spec):
     saver = Saver(model, engine)
     start_step = 0
     # async_ps: the chief restores and uploads to the ps tasks; collective modes: every rank loads the file
-    collective = not (FLAGS.mode == "async_ps" and spec.ps_hosts)
+    collective = xgmi or not (FLAGS.mode == "async_ps" and spec.ps_hosts)
     if FLAGS.resume and (is_chief or collective):
         restored = saver.restore_latest(FLAGS.checkpoint_dir)
         if restored is not None:

@@ -21,8 +21,9 @@ def test_bn_forward_backward(shape, relu, res):
     C = shape[-1]
     y = _rand(*shape, seed=1, scale=1.5, shift=0.3)
     r = _rand(*shape, seed=2) if res else None
-    gamma = torch.rand(C) + 0.5
-    beta = torch.randn(C) * 0.1
+    gen = torch.Generator().manual_seed(C)
+    gamma = torch.rand(C, generator=gen) + 0.5
+    beta = torch.randn(C, generator=gen) * 0.1
     eps, mom = 1e-3, 0.1
     rm, rv = torch.zeros(C), torch.ones(C)
     # reference
@@ -33,6 +34,7 @@ def test_bn_forward_backward(shape, relu, res):
     out, mean, invstd = ref.batch_norm_train(yf, gf, bf, rm_ref, rv_ref, eps, mom)
     if res:
         out = out + rf
+    pre = out.detach().clone()
     if relu:
         out = torch.relu(out)
     dz = _rand(*shape, seed=3)
@@ -51,13 +53,17 @@ def test_bn_forward_backward(shape, relu, res):
     # without a residual the ReLU mask is recomputed from y (zout not read)
     dy, dres, dgamma, dbeta = K.bn_backward(dz.cuda(), yc, z if res else None, m, i, gamma.cuda(), relu, res,
                                             scale=sc, shift=sh)
-    # the reference masks with its own fp32 output; mask from the bf16 output can differ only at |out| ~ 0
+    # the reference masks with its own fp32 output; the mask from the bf16 data can differ only where the
+    # pre-activation is ~ 0 (there a flipped sign changes the element's gradient by its full size): those
+    # elements are left out of the comparison
+    sure = (pre.abs() > 3e-2) if relu else torch.ones_like(pre, dtype=torch.bool)
+    assert sure.float().mean().item() > 0.95
     tol = 3e-2 * (yf.grad.abs().max().item() + 1e-6)
-    assert (dy.float().cpu() - yf.grad).abs().max().item() <= tol
+    assert ((dy.float().cpu() - yf.grad).abs() * sure).max().item() <= tol
     torch.testing.assert_close(dgamma.cpu(), gf.grad, rtol=2e-2, atol=2e-2 * gf.grad.abs().max().item())
     torch.testing.assert_close(dbeta.cpu(), bf.grad, rtol=2e-2, atol=2e-2 * bf.grad.abs().max().item())
     if res:
-        assert (dres.float().cpu() - rf.grad).abs().max().item() <= 2e-2 * rf.grad.abs().max().item()
+        assert ((dres.float().cpu() - rf.grad).abs() * sure).max().item() <= 2e-2 * rf.grad.abs().max().item()
     if relu:
         # the stored sign bitmask is an exact substitute for reading the activation output
         z2, mask = K.bn_apply(yc, sc, sh, True, r.cuda() if res else None, want_mask=True)

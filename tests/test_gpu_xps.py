@@ -1,0 +1,73 @@
+"""GPU-resident parameter server over one-sided peer memory (csrc/hip/xps.hip, parallel/xps.py): rank processes
+sharing one GPU -- IPC-mapped shard regions, mailbox pushes, owner-side fused optimizer, peer pulls, clocks."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "xps_worker.py")
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
+def _launch(mode, world, out_dir, timeout=170):
+    port = _port()
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, mode, str(out_dir)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return procs, outs
+
+
+def _ok(procs, outs, ranks=None):
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        if ranks is None or r in ranks:
+            assert p.returncode == 0 and "XPS_OK" in o, "rank %d:\n%s" % (r, o[-3000:])
+
+
+@pytest.mark.parametrize("opt", ["adam", "momentum"])
+def test_lockstep_rounds_equal_synchronous_data_parallel_bitwise(tmp_path, opt):
+    """staleness 0: pushes of a round summed in rank order by the owner, one optimizer step -> exactly the
+    parameters of all-reduce data parallelism (same fp32 bits), and every replica pulls the same values."""
+    a_p, a_o = _launch("lockstep_" + opt, 2, tmp_path)
+    _ok(a_p, a_o)
+    b_p, b_o = _launch("syncdp_" + opt, 2, tmp_path)
+    for p, o in zip(b_p, b_o):
+        assert p.returncode == 0, o[-3000:]
+    xa = [torch.load(os.path.join(tmp_path, "xps_lockstep_%s_r%d.pt" % (opt, r))) for r in range(2)]
+    sa = [torch.load(os.path.join(tmp_path, "xps_syncdp_%s_r%d.pt" % (opt, r))) for r in range(2)]
+    assert torch.equal(xa[0], xa[1])
+    assert torch.equal(sa[0], sa[1])
+    assert torch.equal(xa[0], sa[0])
+
+
+def test_staleness_bound_holds_and_every_push_is_applied_once(tmp_path):
+    procs, outs = _launch("stale", 3, tmp_path)
+    _ok(procs, outs)
+
+
+def test_dead_worker_does_not_stall_the_others(tmp_path):
+    procs, outs = _launch("dead", 3, tmp_path)
+    assert "XPS_DYING" in outs[2]
+    _ok(procs, outs, ranks=(0, 1))
+
+
+def test_checkpoint_and_restore_through_one_sided_reads(tmp_path):
+    procs, outs = _launch("ckpt", 2, tmp_path)
+    _ok(procs, outs)
