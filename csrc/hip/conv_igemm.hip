@@ -27,286 +27,8 @@
 // stores bf16 rows through LDS so that global stores are 16 B per lane.
 #include "common.h"
 
-struct ConvArgs {
-  const bf16* x;
-  const bf16* w;
-  bf16* y;
-  const float* bias;   // [Cout] or null
-  const bf16* addend;  // optional tensor of the output's shape, added in the epilogue (residual gradient; with the
-                       // bias / ReLU epilogue: the residual of a block, added before the ReLU)
-  const unsigned char* addend_mask;  // optional: one bit per element of addend, only set elements are added
-  float* stats;        // [mtiles][2][Cout] partial (sum, sumsq) or null
-  const bf16* zero;    // >= 16 bytes of zeros, 16-byte aligned
-  const int* taps;     // T entries, (dy << 16) | (dx & 0xffff)
-  int IH, IW, Cin;
-  int OH, OW, Cout;
-  int OYn, OXn;
-  int osy, osx, oy0, ox0;
-  int isy, isx;
-  int T, M, K;
-  unsigned cin_magic;  // ceil(2^32 / Cin)
-  int relu;
-  int dense_out;       // output pixel index == m (no stride/offset mapping)
-  int pointwise;       // 1x1, stride 1, no padding, dense output: input pixel index == m
-  // Data-gradient launches whose output is the incoming gradient dz of a batch-norm layer can emit that
-  // layer's backward partial sums (sum g, sum g*xhat; g = dz gated by the ReLU sign, xhat = (y-mean)*invstd)
-  // into ``stats`` while the output tile is still on chip:
-  const bf16* bn_y;              // the batch-norm input (shape of the output), or null
-  const float* bn_mean;          // [Cout]
-  const float* bn_invstd;        // [Cout]
-  const float* bn_scale;         // [Cout]  (bn_relu == 2: sign recomputed from y*scale+shift)
-  const float* bn_shift;         // [Cout]
-  const unsigned char* bn_mask;  // one bit per output element (bn_relu == 3)
-  int bn_relu;                   // 0: no gating, 2: recompute, 3: stored bits
-  // bias / ReLU epilogue only (inference with folded batch-norm, dense layers):
-  int ldo;                       // channel pitch of the output rows (> Cout: y is a channel slice of a wider tensor)
-  const float* oscale;           // [Cout] multiplier applied to the accumulator before the bias, or null
-};
+#include "conv_epilogue.h"
 
-#define MAX_TAPS 64
-
-template <int BK>
-__device__ __forceinline__ int swz_of_row(int row) {
-  constexpr int S = BK / 8;
-  constexpr int R = 256 / (BK * 2);
-  return (row / R) & (S - 1);
-}
-
-// EPI selects the epilogue at compile time: 0 = plain store (data-gradient, no statistics),
-// 1 = batch-norm partial statistics, 2 = bias (+ optional ReLU), 3 = data-gradient that also emits the
-// batch-norm backward partial sums of the layer its output flows into.
-// Epilogue shared by the kernels below.  ``acc`` is the wave's MT x NT grid of 32x32 accumulators for the
-// tile at (m0, n0); ``w4`` is the wave's index inside its 2x2 group and ``lds_tiles`` that group's LDS
-// region (at least 4 * (BM/2) * EP_PITCH + BN*8 bytes), free for reuse.  ``valid`` is false for a group
-// that has no tile (it still takes part in the barriers).  Bias / ReLU / batch-norm statistics / bf16 rows
-// staged through LDS so that global stores are 16 B per lane.
-#ifndef CONV_NT
-#define CONV_NT 0
-#endif
-// epilogue traffic hints (CONV_NT: bit 0 = non-temporal output stores, bit 1 = non-temporal operand loads)
-__device__ __forceinline__ void out_store(bf16x8* p, bf16x8 v) {
-#if (CONV_NT & 1)
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
-__device__ __forceinline__ bf16x8 epi_load(const bf16x8* p) {
-#if (CONV_NT & 2)
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-
-template <int BM, int BN, int EPI>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[BM / 64][BN / 64], char* lds_tiles,
-                                              int w4, int lane, int m0, int n0, unsigned tile_m, bool valid) {
-  constexpr int WM = BM / 2, WN = BN / 2;
-  constexpr int MT = WM / 32, NT = WN / 32;
-  constexpr int EP_PITCH = WN * 2 + 16;
-  const int wr = w4 >> 1, wc = w4 & 1;
-  const int wid = w4;
-  const int khalf = lane >> 5;
-  const int opix = p.OYn * p.OXn;
-  const int ldo = EPI == 2 ? p.ldo : p.Cout;  // only the bias / ReLU epilogue writes into channel slices
-  // ---- epilogue: bias / relu / bn partial statistics / bf16 rows via LDS ----
-  // Row readback geometry: a wave-instruction covers RPP rows x CPR 16-byte chunks; lane -> (row, chunk)
-  // is the same in every pass, so a lane keeps one chunk column (8 channels).
-  // CPR (chunk slots per row) is the row's chunk count rounded up to a power of two, so that lane -> (row,
-  // chunk) is a shift / mask; for WN = 96 four of the 16 slots are idle.
-  constexpr int CHUNKS = WN / 8;      // 16-byte chunks per row
-  constexpr int CPR = CHUNKS <= 4 ? 4 : (CHUNKS <= 8 ? 8 : 16);
-  constexpr int RPP = 64 / CPR;       // rows per pass
-  constexpr int NP = WM / RPP;        // passes
-  const bool chunk_live = (lane % CPR) < CHUNKS;
-  const int chunk_co = n0 + wc * WN + (lane % CPR) * 8;
-  size_t last_pixel = 0;  // physical output pixel of the latest out_offset() call
-  auto out_offset = [&](int pass, bool& ok) -> size_t {
-    const int m = m0 + wr * WM + pass * RPP + lane / CPR;
-    ok = m < p.M && chunk_co < p.Cout && chunk_live;
-    size_t opixel = 0;
-    if (ok) {
-      if (p.dense_out) {
-        opixel = (size_t)m;
-      } else {
-        int b = m / opix;
-        int rem = m - b * opix;
-        int oy = rem / p.OXn;
-        int ox = rem - oy * p.OXn;
-        opixel = ((size_t)b * p.OH + (oy * p.osy + p.oy0)) * p.OW + (ox * p.osx + p.ox0);
-      }
-    }
-    last_pixel = opixel;
-    return opixel * ldo + chunk_co;
-  };
-  char* ep = lds_tiles + wid * (WM * EP_PITCH);
-  float* xch = (float*)(lds_tiles + 4 * WM * EP_PITCH);  // [2 wave columns][WN][2] exchange area behind the row tiles
-  float st1[NT], st2[NT];
-  const int colq = lane & 31;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int co = n0 + wc * WN + nt * 32 + colq;
-    float bias = 0.f, osc = 1.f;
-    if (EPI == 2 && p.bias != nullptr && co < p.Cout) bias = p.bias[co];
-    if (EPI == 2 && p.oscale != nullptr && co < p.Cout) osc = p.oscale[co];
-    const bool relu = EPI == 2 && p.relu != 0 && p.addend == nullptr;  // with a residual the ReLU follows the add
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float v = acc[mt][nt][j];
-        if (EPI == 2) {
-          v = v * osc + bias;
-          if (relu) v = fmaxf(v, 0.f);
-        }
-        if (EPI == 1) {  // statistics of the fp32 accumulators (rounding to bf16 is unbiased)
-          s1 += v;
-          s2 += v * v;
-        }
-        int r = mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * khalf;
-        *(bf16*)(ep + r * EP_PITCH + (nt * 32 + colq) * 2) = (bf16)v;
-      }
-    }
-    if (EPI == 1) {
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      st1[nt] = s1;
-      st2[nt] = s2;
-      // the lower wave row parks its sums; the upper one adds them after the barrier (one row per tile)
-      if (wr == 1 && khalf == 0) {
-        xch[((wc * NT + nt) * 32 + colq) * 2] = s1;
-        xch[((wc * NT + nt) * 32 + colq) * 2 + 1] = s2;
-      }
-    }
-  }
-  __syncthreads();
-  if (EPI == 1 && wr == 0 && khalf == 0 && valid) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int co = n0 + wc * WN + nt * 32 + colq;
-      if (co < p.Cout) {
-        const size_t prow = (size_t)tile_m * 2;
-        p.stats[prow * p.Cout + co] = st1[nt] + xch[((wc * NT + nt) * 32 + colq) * 2];
-        p.stats[(prow + 1) * p.Cout + co] = st2[nt] + xch[((wc * NT + nt) * 32 + colq) * 2 + 1];
-      }
-    }
-  }
-
-  float bs1[8], bs2[8], bmu[8], bis[8], bsc[8], bsh[8];
-  if (EPI == 3) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool ok = chunk_co + j < p.Cout && chunk_live;
-      bs1[j] = bs2[j] = 0.f;
-      bmu[j] = ok ? p.bn_mean[chunk_co + j] : 0.f;
-      bis[j] = ok ? p.bn_invstd[chunk_co + j] : 0.f;
-      bsc[j] = (ok && p.bn_relu == 2) ? p.bn_scale[chunk_co + j] : 0.f;
-      bsh[j] = (ok && p.bn_relu == 2) ? p.bn_shift[chunk_co + j] : 0.f;
-    }
-  }
-  if (EPI == 1 || EPI == 2) {
-    // forward: plain coalesced row stores
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-      bool ok;
-      const size_t off = out_offset(pass, ok);
-      if (ok) {
-        const int r = pass * RPP + lane / CPR;
-        bf16x8 v = *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16);
-        if (EPI == 2 && p.addend != nullptr) {
-          // inference residual block: act(conv * scale + shift + residual); the residual is dense ([.., Cout])
-          const bf16x8 res = epi_load((const bf16x8*)(p.addend + last_pixel * p.Cout + chunk_co));
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float f = (float)v[j] + (float)res[j];
-            v[j] = (bf16)(p.relu ? fmaxf(f, 0.f) : f);
-          }
-        }
-        out_store((bf16x8*)(p.y + off), v);
-      }
-    }
-  } else {
-    // data gradient: the readback may add a residual gradient (optionally gated by a bitmask) and fold
-    // the batch-norm backward sums.  Passes are handled in groups: all global loads of a group are
-    // requested before any is consumed, so a tile pays the memory latency once per group, not per pass.
-    constexpr int G = NP >= 4 ? 4 : NP;
-    const bool has_add = p.addend != nullptr;
-    const bool has_addm = p.addend_mask != nullptr;
-#pragma unroll
-    for (int g0 = 0; g0 < NP; g0 += G) {
-      size_t ooff[G];
-      bool ook[G];
-      bf16x8 addv[G], bnyv[G];
-      unsigned addm[G], bnm[G];
-#pragma unroll
-      for (int i = 0; i < G; ++i) {
-        ooff[i] = out_offset(g0 + i, ook[i]);
-        const size_t off = ook[i] ? ooff[i] : 0;  // idle lanes read an in-range dummy
-        if (has_add) {
-          addv[i] = epi_load((const bf16x8*)(p.addend + off));
-          addm[i] = has_addm ? (unsigned)p.addend_mask[off >> 3] : 0xffu;
-        }
-        if (EPI == 3) {
-          bnyv[i] = epi_load((const bf16x8*)(p.bn_y + off));
-          bnm[i] = p.bn_relu == 3 ? (unsigned)p.bn_mask[off >> 3] : 0xffu;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < G; ++i) {
-        if (!ook[i]) continue;
-        const int r = (g0 + i) * RPP + lane / CPR;
-        bf16x8 v = *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16);
-        if (has_add) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (((addm[i] >> j) & 1u) ? (float)addv[i][j] : 0.f));
-        }
-        out_store((bf16x8*)(p.y + ooff[i]), v);
-        if (EPI == 3) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float yf = (float)bnyv[i][j];
-            float g = (float)v[j];  // the rounded value, the one the elementwise backward pass will read
-            if (p.bn_relu == 2 && !(yf * bsc[j] + bsh[j] > 0.f)) g = 0.f;
-            if (!((bnm[i] >> j) & 1u)) g = 0.f;
-            bs1[j] += g;
-            bs2[j] += g * ((yf - bmu[j]) * bis[j]);
-          }
-        }
-      }
-    }
-  }
-  if (EPI == 3) {
-    // lanes that share a chunk column differ in the lane bits above log2(CPR): fold those
-#pragma unroll
-    for (int sh = CPR; sh < 64; sh <<= 1) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        bs1[j] += __shfl_xor(bs1[j], sh, 64);
-        bs2[j] += __shfl_xor(bs2[j], sh, 64);
-      }
-    }
-    const int co = chunk_co;
-    float* mine = xch + (wc * WN + (lane % CPR) * 8) * 2;
-    if (wr == 1 && lane < CHUNKS) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        mine[j * 2] = bs1[j];
-        mine[j * 2 + 1] = bs2[j];
-      }
-    }
-    __syncthreads();
-    if (wr == 0 && lane < CHUNKS && co < p.Cout && valid) {
-      const size_t prow = (size_t)tile_m * 2;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        p.stats[prow * p.Cout + co + j] = bs1[j] + mine[j * 2];
-        p.stats[(prow + 1) * p.Cout + co + j] = bs2[j] + mine[j * 2 + 1];
-      }
-    }
-  }
-}
 
 // Timing-only builds for attributing main-loop time (results are wrong): -DDTFA_DBG=1 drops the global
 // loads of the main loop, =2 replaces the MFMAs by one scalar FMA per fragment pair, =3 both.
@@ -373,7 +95,9 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
   const int cslot = slot ^ swz_of_row<BK>(wid * RPI + row_in_inst);  // same for every i
 
   const bf16* abase[NA];
+  const bf16* abase2[NA];   // pointwise launches with a second operand: rows of x2
   int aiy[NA], aix[NA];
+  const int K1 = p.K1, C2 = p.K - p.K1;
   const int opix = p.OYn * p.OXn;
   // 1x1 / stride-1 / unpadded: input pixel == output pixel == m, no decode and no bounds checks
 #pragma unroll
@@ -382,7 +106,8 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
     if (pointwise) {
       aiy[i] = m < p.M ? 0 : -(1 << 24);
       aix[i] = 0;
-      abase[i] = p.x + (size_t)(m < p.M ? m : 0) * p.Cin;
+      abase[i] = p.x + (size_t)(m < p.M ? m : 0) * K1;
+      abase2[i] = p.x2 != nullptr ? p.x2 + (size_t)(m < p.M ? m : 0) * C2 - K1 : abase[i];
     } else if (m < p.M) {
       int b = m / opix;
       int rem = m - b * opix;
@@ -418,7 +143,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
     if (pointwise) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const bf16* src = (kvalid && aiy[i] == 0) ? abase[i] + kc8 : p.zero;
+        const bf16* src = (kvalid && aiy[i] == 0) ? (kc8 < K1 ? abase[i] : abase2[i]) + kc8 : p.zero;
         glds16(src, sa + (i * 4 + wid) * 1024);
       }
     } else {
@@ -660,10 +385,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
 
 template <int BM, int BN, int BK, int NST, int WG = 1>
 static int launch_conv_epi(const ConvArgs& a, hipStream_t stream) {
-  if (a.bn_y != nullptr) return launch_conv<BM, BN, BK, 3, NST, WG>(a, stream);
+  if (a.bn_y != nullptr || a.bn_gate_store) return launch_conv<BM, BN, BK, 3, NST, WG>(a, stream);
   if (a.stats != nullptr) return launch_conv<BM, BN, BK, 1, NST, WG>(a, stream);
   if (a.bias != nullptr || a.relu || a.oscale != nullptr || a.ldo != a.Cout)
-    return launch_conv<BM, BN, BK, 2, NST, WG>(a, stream);
+    return launch_conv<BM, BN, BK, 2, NST, WG>(a, stream);  // (omask rides on relu)
   return launch_conv<BM, BN, BK, 0, NST, WG>(a, stream);
 }
 
@@ -676,13 +401,19 @@ extern "C" int dtfa_conv_stats_rows(int M, int bm) {
 
 extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int nst, hipStream_t stream) {
   if (a->Cin % 8 != 0 || a->Cout % 8 != 0 || a->T > MAX_TAPS || a->T < 1) return -1;
-  if (a->K != a->T * a->Cin || a->K >= (1 << 16)) return -2;
+  if ((a->x2 == nullptr && a->K != a->T * a->Cin) || a->K >= (1 << 16)) return -2;
   if ((long long)a->IH * a->IW >= (1ll << 24) || (long long)a->IH * a->IW * a->Cin >= (1ll << 32)) return -2;
   if (a->stats != nullptr && a->bias != nullptr) return -4;
   // a residual in the bias / ReLU (forward) epilogue: no bitmask, no statistics
   const bool fwd_residual = a->addend != nullptr && (a->bias != nullptr || a->relu || a->oscale != nullptr);
   if (fwd_residual && (a->addend_mask != nullptr || a->stats != nullptr || a->bn_y != nullptr)) return -4;
-  if (a->addend != nullptr && !fwd_residual && a->stats != nullptr && a->bn_y == nullptr) return -4;
+  if (a->addend != nullptr && !fwd_residual && a->stats != nullptr && a->bn_y == nullptr && !a->bn_gate_store) return -4;
+  if (a->bn_gate_store && (a->bn_relu != 3 || a->bn_mask == nullptr || a->stats == nullptr || a->bias != nullptr || a->relu))
+    return -5;
+  if (a->omask != nullptr && (!a->relu || a->ldo != a->Cout || a->stats != nullptr || a->bn_y != nullptr)) return -6;
+  if (a->dbias != nullptr && (a->bias != nullptr || a->relu || a->oscale != nullptr)) return -4;
+  if (a->x2 != nullptr && (!a->pointwise || a->K1 <= 0 || a->K1 >= a->K || a->K1 % 8 != 0)) return -7;
+  if (a->x2 == nullptr && a->K1 != a->K) return -7;
   if (a->bn_y != nullptr) {
     if (a->stats == nullptr || a->bn_mean == nullptr || a->bn_invstd == nullptr || a->bias != nullptr || a->relu) return -5;
     if (a->bn_relu == 2 && (a->bn_scale == nullptr || a->bn_shift == nullptr)) return -5;

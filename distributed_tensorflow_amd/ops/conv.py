@@ -225,9 +225,9 @@ def pick_wgrad_tile(M: int, cout: int, K: int, cin: int = 0) -> Tuple[int, int, 
 # --------------------------------------------------------------------------
 def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, osx, oy0, ox0, isy, isx, B,
                   cin_magic, bias=None, relu=False, stats=False, addend=None, zero_taps=False, addend_mask=None,
-                  bn_tap=None, oscale=None, ldo=0):
+                  bn_tap=None, oscale=None, ldo=0, omask=None, dbias=None, x2=None):
     M = B * oyn * oxn
-    K = T * cin
+    K = T * cin + (x2.shape[-1] if x2 is not None else 0)
     dense_out = osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow
     bm, bn, bk, nst = pick_fwd_tile(M, cout, K, dense_out)
     L = hipk.lib()
@@ -241,10 +241,13 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     a.addend = hipk.ptr(addend)
     a.addend_mask = hipk.ptr(addend_mask)
     if bn_tap is not None:
-        a.bn_y, a.bn_mean, a.bn_invstd = bn_tap.y.data_ptr(), bn_tap.mean.data_ptr(), bn_tap.invstd.data_ptr()
+        a.bn_y, a.bn_mean, a.bn_invstd = hipk.ptr(bn_tap.y), hipk.ptr(bn_tap.mean), hipk.ptr(bn_tap.invstd)
         a.bn_scale, a.bn_shift, a.bn_mask = hipk.ptr(bn_tap.scale), hipk.ptr(bn_tap.shift), hipk.ptr(bn_tap.mask)
         a.bn_relu = bn_tap.relu_mode
+        a.bn_gate_store = 1 if bn_tap.gate_store else 0
     a.stats = hipk.ptr(part)
+    a.omask, a.dbias, a.x2 = hipk.ptr(omask), hipk.ptr(dbias), hipk.ptr(x2)
+    a.K1 = T * cin
     a.zero = hipk.zero_page(x.device).data_ptr()
     a.taps = taps.data_ptr()
     a.IH, a.IW, a.Cin = ih, iw, cin
@@ -268,8 +271,12 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
 
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[torch.Tensor] = None,
              relu: bool = False, want_stats: bool = False, scale: Optional[torch.Tensor] = None,
-             out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None):
+             out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+             mask_out: Optional[torch.Tensor] = None):
     """x [B,IH,IW,Cin] bf16, w [Cout,KH,KW,Cin] bf16 -> (y [B,OH,OW,Cout] bf16, stats partials or None).
+
+    ``mask_out`` (uint8 [numel / 8], with ``relu`` and a dense output) receives the sign of the activation, one
+    bit per element: what a training step keeps of a ReLU output for its backward pass.
 
     ``scale`` / ``bias`` ([Cout] fp32) turn the epilogue into ``act(conv * scale + bias)`` -- a convolution with
     its inference-mode batch-norm folded in; ``residual`` ([B,OH,OW,Cout] bf16, with ``bias`` or ``scale``) is added
@@ -308,40 +315,188 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
                 or y.stride(3) != 1 or ldo < plan.cout or ldo % 8 or y.stride(1) != plan.ow * ldo
                 or y.stride(0) != plan.oh * plan.ow * ldo or y.data_ptr() % 16 or want_stats):
             raise ValueError("out must be a 16-byte aligned channel slice of a contiguous NHWC bf16 tensor")
+    if mask_out is not None:
+        if not relu or out is not None or mask_out.dtype != torch.uint8 or not mask_out.is_contiguous() \
+                or mask_out.numel() * 8 != y.numel() or mask_out.device != x.device:
+            raise ValueError("mask_out needs a ReLU, a dense output and numel / 8 bytes")
     part = _launch_igemm(x, w, y, plan.fwd_taps, plan.T, plan.ih, plan.iw, plan.cin, plan.oh, plan.ow, plan.cout,
                          plan.oh, plan.ow, 1, 1, 0, 0, plan.sy, plan.sx, B, plan.cin_magic, bias, relu, want_stats,
-                         addend=residual, zero_taps=plan.is_pointwise, oscale=scale, ldo=ldo)
+                         addend=residual, zero_taps=plan.is_pointwise, oscale=scale, ldo=ldo, omask=mask_out)
     return y, part
+
+
+# --------------------------------------------------------------------------
+# pointwise GEMM with a fused batch-norm prologue on its pixel operand (csrc/hip/conv_pro.hip)
+# --------------------------------------------------------------------------
+PRO_FWD, PRO_FWD_RES, PRO_BWD_RELU, PRO_BWD_MASK, PRO_BWD_PLAIN = 1, 2, 3, 4, 5
+_PRO = os.environ.get("DTFA_CONV_PRO", "1") == "1"
+_PRO_MIN_ROWS = int(os.environ.get("DTFA_CONV_PRO_MIN_ROWS", str(1 << 16)))
+
+
+def pick_pro_tile(M: int, n: int, K: int, pro: int) -> Tuple[int, int]:
+    """(BN, BK) of the prologue kernel.  k-tiles of 64 channels: every row access is then a whole 128-byte line
+    (with 32 the two halves of a line were fetched by different k-tiles: 4.0 instead of 5.2 TB/s).  Outputs wider than 128 columns take several column tiles: their
+    workgroups run side by side on one XCD (consecutive block ids), so the repeated operand reads are L2 hits;
+    only the first column tile writes the side output."""
+    forced = _env_tile("DTFA_PRO_TILE")
+    if forced:
+        return forced[0], forced[1]
+    return (64, 64) if n <= 64 else (128, 64)
+
+
+def pro_supported(plan: "ConvPlan", B: int, dgrad: bool) -> bool:
+    """The prologue kernel serves 1x1 / stride-1 / unpadded layers at sizes where the elementwise passes are
+    bound by HBM (many rows); small problems keep the separate passes (fewer, better-filled launches)."""
+    return _PRO and plan.is_pointwise and B * plan.oh * plan.ow >= _PRO_MIN_ROWS
+
+
+def conv_pro(a_src: torch.Tensor, w2d: torch.Tensor, n_out: int, pro: int, c0: torch.Tensor, c1: torch.Tensor,
+             c2: Optional[torch.Tensor] = None, src2: Optional[torch.Tensor] = None,
+             gate: Optional[torch.Tensor] = None, gscale: Optional[torch.Tensor] = None,
+             gshift: Optional[torch.Tensor] = None, side: Optional[torch.Tensor] = None,
+             side_mask: Optional[torch.Tensor] = None, relu: bool = False, want_stats: bool = False,
+             addend: Optional[torch.Tensor] = None, addend_mask: Optional[torch.Tensor] = None,
+             bn_tap: Optional["BnBackwardTap"] = None, out: Optional[torch.Tensor] = None):
+    """``out[m][n] = sum_k a[m][k] * w2d[n][k]`` with ``a = prologue(a_src, src2, ...)`` computed on the fly:
+
+    * ``PRO_FWD``       ``a = act(a_src * c0 + c1)``
+    * ``PRO_FWD_RES``   ``a = relu(a_src * c0 + c1 + src2)``
+    * ``PRO_BWD_RELU``  ``g = a_src * (src2 * gscale + gshift > 0)``,  ``a = c0 * g + c1 * src2 + c2``
+    * ``PRO_BWD_MASK``  ``g = a_src`` where the bit of ``gate`` is set,  ``a = c0 * g + c1 * src2 + c2``
+    * ``PRO_BWD_PLAIN`` ``g = a_src``,                                  ``a = c0 * g + c1 * src2 + c2``
+
+    ``a_src`` is ``[..., K]`` bf16 (flattened to rows), coefficients are fp32 ``[K]``.  ``side`` (same shape as
+    ``a_src``) receives ``a``; ``side_mask`` (forward modes with ReLU) one bit per element, ``a > 0``.  The output
+    options are those of the convolution kernel: batch-norm statistics partials (``want_stats``), an addend
+    (optionally bit-gated) and the batch-norm backward sums of the layer below (``bn_tap``).
+    Returns ``(out [..., n_out], partials or None)``."""
+    hipk.require(a_src, torch.bfloat16, "a_src")
+    hipk.require(w2d, torch.bfloat16, "w2d")
+    K = a_src.shape[-1]
+    M = a_src.numel() // K
+    if w2d.numel() != n_out * K or K % 8 or n_out % 8:
+        raise ValueError("prologue GEMM: weight / channel sizes")
+    if M >= 1 << 31:
+        raise ValueError("too many rows for 32-bit row indices")
+    bwd = pro >= PRO_BWD_RELU
+    need = [("c0", c0), ("c1", c1)] + ([("c2", c2)] if bwd else [])
+    if pro == PRO_BWD_RELU:
+        need += [("gscale", gscale), ("gshift", gshift)]
+    for nm, t in need:
+        if t is None:
+            raise ValueError("prologue GEMM: %s missing" % nm)
+        hipk.require(t, torch.float32, nm)
+        if t.numel() != K:
+            raise ValueError("prologue GEMM: %s needs K entries" % nm)
+    if pro != PRO_FWD:
+        if src2 is None:
+            raise ValueError("prologue GEMM: second operand missing")
+        hipk.require(src2, torch.bfloat16, "src2")
+        if src2.shape != a_src.shape:
+            raise ValueError("prologue GEMM: operand shapes differ")
+    if pro == PRO_BWD_MASK:
+        if gate is None or gate.dtype != torch.uint8 or gate.numel() * 8 != a_src.numel() or not gate.is_contiguous():
+            raise ValueError("prologue GEMM: gate bitmask size")
+    if side is not None:
+        hipk.require(side, torch.bfloat16, "side")
+        if side.shape != a_src.shape:
+            raise ValueError("prologue GEMM: side output shape")
+    if side_mask is not None:
+        if bwd or not (relu or pro == PRO_FWD_RES) or side_mask.dtype != torch.uint8 \
+                or side_mask.numel() * 8 != a_src.numel() or not side_mask.is_contiguous():
+            raise ValueError("prologue GEMM: side bitmask")
+    oshape = tuple(a_src.shape[:-1]) + (n_out,)
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.bfloat16, device=a_src.device)
+    else:
+        hipk.require(out, torch.bfloat16, "out")
+        if tuple(out.shape) != oshape:
+            raise ValueError("prologue GEMM: output shape")
+    if addend is not None:
+        hipk.require(addend, torch.bfloat16, "addend")
+        if tuple(addend.shape) != oshape or want_stats:
+            raise ValueError("prologue GEMM: addend shape")
+        if addend_mask is not None and (addend_mask.dtype != torch.uint8 or addend_mask.numel() * 8 != addend.numel()):
+            raise ValueError("prologue GEMM: addend bitmask size")
+    elif addend_mask is not None:
+        raise ValueError("addend_mask without addend")
+    if bn_tap is not None:
+        if want_stats:
+            raise ValueError("prologue GEMM: statistics and batch-norm tap are exclusive")
+        bn_tap.validate(oshape, n_out)
+    L = hipk.lib()
+    bn, bk = pick_pro_tile(M, n_out, K, pro)
+    part = None
+    if want_stats or bn_tap is not None:
+        part = torch.empty((L.dtfa_conv_stats_rows(M, 128), 2, n_out), dtype=torch.float32, device=a_src.device)
+    a = hipk.ConvArgs()
+    a.x, a.w, a.y = a_src.data_ptr(), w2d.data_ptr(), out.data_ptr()
+    a.addend, a.addend_mask = hipk.ptr(addend), hipk.ptr(addend_mask)
+    if bn_tap is not None:
+        a.bn_y, a.bn_mean, a.bn_invstd = bn_tap.y.data_ptr(), bn_tap.mean.data_ptr(), bn_tap.invstd.data_ptr()
+        a.bn_scale, a.bn_shift, a.bn_mask = hipk.ptr(bn_tap.scale), hipk.ptr(bn_tap.shift), hipk.ptr(bn_tap.mask)
+        a.bn_relu = bn_tap.relu_mode
+    a.stats = hipk.ptr(part)
+    a.zero = hipk.zero_page(a_src.device).data_ptr()
+    a.IH, a.IW, a.Cin = 1, 1, K
+    a.OH, a.OW, a.Cout = 1, 1, n_out
+    a.OYn, a.OXn = 1, 1
+    a.osy = a.osx = a.isy = a.isx = 1
+    a.T, a.M, a.K, a.K1 = 1, M, K, K
+    a.cin_magic = _magic(K)
+    a.ldo = n_out
+    a.dense_out = a.pointwise = 1
+    q = hipk.ProArgs()
+    q.src2, q.gate = hipk.ptr(src2), hipk.ptr(gate)
+    q.c0, q.c1, q.c2 = c0.data_ptr(), c1.data_ptr(), hipk.ptr(c2)
+    q.gscale, q.gshift = hipk.ptr(gscale), hipk.ptr(gshift)
+    q.side, q.side_mask = hipk.ptr(side), hipk.ptr(side_mask)
+    q.relu = 1 if relu else 0
+    hipk.check(L.dtfa_conv_pro(C.byref(a), C.byref(q), pro, bn, bk, hipk.stream()), "conv_pro %d %dx%d" % (pro, bn, bk))
+    return out, part
 
 
 class BnBackwardTap:
     """What a data-gradient kernel needs to emit the backward partial sums of the batch-norm layer its
     output flows into: that layer's input ``y`` and statistics, and how its ReLU sign is obtained
     (``relu_mode`` 0: no activation, 2: recomputed from ``y*scale+shift``, 3: stored bits in ``mask``).
-    The producer of the gradient stores the partial sums in ``partials``."""
+    The producer of the gradient stores the partial sums in ``partials``.
 
-    __slots__ = ("y", "mean", "invstd", "scale", "shift", "mask", "relu_mode", "partials")
+    A tap with ``gate_store`` (a layer whose batch-norm is folded through its convolution, see
+    ``ops.functional._ExpandBnResFn``) asks for less and more: no ``y`` (only ``sum g`` is emitted), and the
+    producer *stores* the gated gradient ``g`` instead of the raw one; it then sets ``gated``."""
+
+    __slots__ = ("y", "mean", "invstd", "scale", "shift", "mask", "relu_mode", "partials", "gate_store", "gated")
 
     def __init__(self):
         self.y = self.mean = self.invstd = self.scale = self.shift = self.mask = self.partials = None
         self.relu_mode = 0
+        self.gate_store = self.gated = False
 
     @property
     def armed(self) -> bool:
-        return self.y is not None
+        return self.y is not None or (self.gate_store and self.mask is not None)
 
     def clear(self) -> None:
         """Drop the tensor references (the autograd graph may outlive the backward pass of a layer)."""
         self.y = self.mean = self.invstd = self.scale = self.shift = self.mask = self.partials = None
+        self.gate_store = self.gated = False
 
     def validate(self, shape, channels: int) -> None:
-        if tuple(self.y.shape) != tuple(shape) or self.y.dtype != torch.bfloat16 or not self.y.is_contiguous():
-            raise ValueError("batch-norm tap does not match the gradient's shape")
-        for t in (self.mean, self.invstd) + ((self.scale, self.shift) if self.relu_mode == 2 else ()):
-            if t is None or t.dtype != torch.float32 or t.numel() != channels:
-                raise ValueError("batch-norm tap statistics have the wrong size")
+        n = 1
+        for d in shape:
+            n *= d
+        if self.gate_store:
+            if self.y is not None or self.relu_mode != 3:
+                raise ValueError("a gate-and-store tap carries sign bits only")
+        else:
+            if tuple(self.y.shape) != tuple(shape) or self.y.dtype != torch.bfloat16 or not self.y.is_contiguous():
+                raise ValueError("batch-norm tap does not match the gradient's shape")
+            for t in (self.mean, self.invstd) + ((self.scale, self.shift) if self.relu_mode == 2 else ()):
+                if t is None or t.dtype != torch.float32 or t.numel() != channels:
+                    raise ValueError("batch-norm tap statistics have the wrong size")
         if self.relu_mode == 3 and (self.mask is None or self.mask.dtype != torch.uint8
-                                    or self.mask.numel() * 8 != self.y.numel()):
+                                    or self.mask.numel() * 8 != n):
             raise ValueError("batch-norm tap bitmask has the wrong size")
         if self.relu_mode not in (0, 2, 3):
             raise ValueError("bad relu_mode")
@@ -353,12 +508,33 @@ def dgrad_can_tap(plan: ConvPlan) -> bool:
 
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Optional[torch.Tensor] = None,
-               addend_mask: Optional[torch.Tensor] = None, bn_tap: Optional[BnBackwardTap] = None) -> torch.Tensor:
+               addend_mask: Optional[torch.Tensor] = None, bn_tap: Optional[BnBackwardTap] = None,
+               wd: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None,
+               dbias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dy [B,OH,OW,Cout] -> dx [B,IH,IW,Cin] (+ ``addend``, e.g. the gradient arriving over a
     residual connection, fused into the epilogue instead of a separate add pass; ``addend_mask`` holds
-    one bit per element of ``addend`` and only set elements are added)."""
+    one bit per element of ``addend`` and only set elements are added).
+
+    Pointwise layers only: ``wd`` ([Cin, K] bf16) replaces the permuted weight matrix; with ``x2`` ([B,OH,OW,C2]
+    bf16) the reduction runs over ``[dy | x2]`` (K = Cout + C2), i.e. ``dx = dy @ wd[:, :Cout].T + x2 @
+    wd[:, Cout:].T``; ``dbias`` ([Cin] fp32) is added before rounding."""
     hipk.require(dy, torch.bfloat16, "dy")
     hipk.require(w, torch.bfloat16, "w")
+    if wd is not None or x2 is not None or dbias is not None:
+        if not plan.is_pointwise:
+            raise ValueError("explicit data-gradient matrices are for pointwise layers")
+        c2 = 0
+        if x2 is not None:
+            hipk.require(x2, torch.bfloat16, "x2")
+            c2 = x2.shape[-1]
+            if tuple(x2.shape[:-1]) != tuple(dy.shape[:-1]) or c2 % 8:
+                raise ValueError("second data-gradient operand shape")
+        if wd is None or wd.dtype != torch.bfloat16 or not wd.is_contiguous() or tuple(wd.shape) != (plan.cin, plan.cout + c2):
+            raise ValueError("explicit data-gradient matrix must be [Cin, Cout + C2] bf16")
+        if dbias is not None:
+            hipk.require(dbias, torch.float32, "dbias")
+            if dbias.numel() != plan.cin:
+                raise ValueError("data-gradient bias size")
     B = dy.shape[0]
     if tuple(dy.shape[1:]) != (plan.oh, plan.ow, plan.cout):
         raise ValueError("dy shape %s does not match plan" % (tuple(dy.shape),))
@@ -384,14 +560,19 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Option
     else:
         dx = torch.empty((B, plan.ih, plan.iw, plan.cin), dtype=torch.bfloat16, device=dy.device)
     for ph in plan.phases:
-        wd = torch.empty((plan.cin, ph.T * plan.cout), dtype=torch.bfloat16, device=dy.device)
-        hipk.check(L.dtfa_weight_permute(w.data_ptr(), wd.data_ptr(), ph.src_tap.data_ptr(), plan.cout, plan.T,
-                                         plan.cin, ph.T, hipk.stream()), "weight_permute")
-        part = _launch_igemm(dy, wd, dx, ph.taps, ph.T, plan.oh, plan.ow, plan.cout, plan.ih, plan.iw, plan.cin,
+        if wd is None:
+            wp = torch.empty((plan.cin, ph.T * plan.cout), dtype=torch.bfloat16, device=dy.device)
+            hipk.check(L.dtfa_weight_permute(w.data_ptr(), wp.data_ptr(), ph.src_tap.data_ptr(), plan.cout, plan.T,
+                                             plan.cin, ph.T, hipk.stream()), "weight_permute")
+        else:
+            wp = wd
+        part = _launch_igemm(dy, wp, dx, ph.taps, ph.T, plan.oh, plan.ow, plan.cout, plan.ih, plan.iw, plan.cin,
                              ph.OYn, ph.OXn, plan.sy, plan.sx, ph.oy0, ph.ox0, 1, 1, B, plan.cout_magic,
-                             addend=addend, zero_taps=plan.is_pointwise, addend_mask=addend_mask, bn_tap=bn_tap)
+                             addend=addend, zero_taps=plan.is_pointwise, addend_mask=addend_mask, bn_tap=bn_tap,
+                             x2=x2, dbias=dbias)
         if bn_tap is not None:
             bn_tap.partials = part
+            bn_tap.gated = bn_tap.gate_store
     return dx
 
 

@@ -366,6 +366,123 @@ class _ConvBnActFn(Function):
         return gx, gw, gg, gb, dres, None, None, None, None, None, None, None, None, None
 
 
+# ----------------------------------------------------------------------------
+# expanding 1x1 conv + batch-norm + residual + ReLU with the normalisation folded THROUGH the convolution
+# ----------------------------------------------------------------------------
+# The tail of a bottleneck block, z = relu(bn(x W^T) + r) with x [M, C] and W [N, C], N = 4C, moves most of the
+# block's bytes when done as conv -> stats -> apply: the N-wide convolution output y is written, re-read for the
+# normalisation, kept for the backward pass and read there three more times.  But y is *linear* in the narrow
+# tensor x, so everything the batch-norm needs of it can be had from C-wide quantities:
+#
+#   forward   S = x^T x (C x C), s = x^T 1:    mean = W s / M,  E[y^2]_n = w_n S w_n^T / M
+#             -> scale a, shift b ->  ONE kernel: z = relu((x W^T) a + b + r), sign bits alongside; y never exists.
+#   backward  with g = dz gated by the sign bits and P = g^T x (N x C, the ordinary weight-gradient GEMM on g):
+#             dbeta = sum_m g,   sum_m g y = rowsum(W * P)  ->  dgamma and the coefficients of dy = c0 g + c1 y + c2
+#             dW = dy^T x = diag(c0) P + diag(c1) W S + c2 s^T
+#             dx = dy W   = g (diag(c0) W) + x (W^T diag(c1) W) + 1 (c2^T W)      -- one GEMM over [g | x]
+#
+# Traffic of the block tail in units of one C-wide tensor sweep: forward 17.25 -> ~11, backward 27 -> 12 (and the
+# stored activations shrink by the N-wide y).  The gated gradient g is written directly by the data-gradient
+# kernel that produces dz (BnBackwardTap.gate_store), which also emits sum_m g.
+def _col_sums(x: torch.Tensor) -> torch.Tensor:
+    return K.reduce_partials(K.bn_stats_partials(x), max_rows=64, direct_rows=0)[:, 0, :].sum(0)
+
+
+class _ExpandBnResFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, plan, run_mean, run_var, eps, momentum, params, links):
+        need_grad = any(ctx.needs_input_grad)
+        N, C = plan.cout, plan.cin
+        M = x.numel() // C
+        gplan = cv.get_plan(plan.ih, plan.iw, C, C, 1, 1, 1, 1, (0, 0, 0, 0), x.device)
+        S = torch.empty((C, C), dtype=F32, device=x.device)
+        cv.conv_wgrad(x, x, gplan, out=S)
+        s = _col_sums(x)
+        W32 = weight.view(N, C).float()
+        T = W32 @ S
+        mean = (W32 @ s) / M
+        var = ((T * W32).sum(1) / M - mean * mean).clamp_min_(0.0)
+        invstd = torch.rsqrt(var + eps)
+        scale = invstd * gamma if gamma is not None else invstd
+        shift = beta - mean * scale
+        if run_mean is not None:
+            run_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+            run_var.mul_(1.0 - momentum).add_(var, alpha=momentum * (M / (M - 1.0) if M > 1 else 1.0))
+        mask = torch.empty(M * N // 8, dtype=torch.uint8, device=x.device) if need_grad else None
+        z, _ = cv.conv_fwd(x, weight, plan, bias=shift, relu=True, scale=scale, residual=residual, mask_out=mask)
+        ctx.plan, ctx.params, ctx.links = plan, params, links
+        ctx.has_res = residual is not None
+        if need_grad and links.output_tap is not None:
+            tap = links.output_tap
+            tap.clear()
+            tap.mask, tap.relu_mode, tap.gate_store = mask, 3, True
+        if need_grad:
+            ctx.save_for_backward(x, weight, mask, gamma, mean, invstd, scale, T, s)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight, mask, gamma, mean, invstd, scale, T, s = ctx.saved_tensors
+        plan, links = ctx.plan, ctx.links
+        wparam, gparam, bparam = ctx.params
+        N, C = plan.cout, plan.cin
+        M = x.numel() // C
+        dz = dz.contiguous()
+        tap = links.output_tap
+        if tap is not None and tap.gated and tap.partials is not None:
+            g = dz   # the producer of dz stored it gated and summed it
+            sum_g = K.reduce_partials(tap.partials, max_rows=64, direct_rows=0)[:, 0, :].sum(0)
+        else:
+            g = K.mask_mul(dz, mask)
+            sum_g = _col_sums(g)
+        if tap is not None:
+            tap.clear()
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[4]:
+            if links.residual_grad is not None:
+                links.residual_grad.grad, links.residual_grad.mask = g, None  # already gated: added without a mask
+            else:
+                dres = g   # (a producer of the residual that waits for sign bits in ``residual_mask`` gets none)
+        P = torch.empty((N, C), dtype=F32, device=x.device)
+        cv.conv_wgrad(x, g, plan, out=P)
+        W32 = weight.view(N, C).float()
+        dbeta = sum_g
+        dgamma = invstd * ((W32 * P).sum(1) - mean * sum_g)
+        c0 = scale
+        c1 = -c0 * invstd * (dgamma / M)
+        c2 = -c0 * (sum_g / M) - c1 * mean
+        gw = gg = gb = gx = None
+        if ctx.needs_input_grad[1]:
+            dW = (c0[:, None] * P).addcmul_(c1[:, None], T).addcmul_(c2[:, None], s[None, :])
+            gw = _deliver_small(wparam if wparam is not None else weight, dW)
+            if gw is not None:
+                gw = gw.view(weight.shape)
+        if gamma is not None and ctx.needs_input_grad[2]:
+            gg = _deliver_small(gparam if gparam is not None else gamma, dgamma)
+        if ctx.needs_input_grad[3]:
+            gb = _deliver_small(bparam, dbeta) if bparam is not None else dbeta
+        if ctx.needs_input_grad[0]:
+            c1W = c1[:, None] * W32
+            wd = torch.cat(((c0[:, None] * W32).t(), c1W.t() @ W32), dim=1).to(BF16).contiguous()  # [C, N + C]
+            q = W32.t() @ c2
+            itap = links.input_tap
+            if itap is not None and not (itap.armed and cv.dgrad_can_tap(plan)):
+                itap = None
+            gx = cv.conv_dgrad(g, weight, plan, bn_tap=itap, wd=wd, x2=x, dbias=q)
+        return gx, gw, gg, gb, dres, None, None, None, None, None, None, None
+
+
+EXPAND_FOLD = os.environ.get("DTFA_EXPAND_FOLD", "1") == "1"
+
+
+def _expand_fold_ok(plan, x, residual, relu, training, links) -> bool:
+    """The folded form needs a 1x1 / stride-1 layer that widens (C -> N > C: the C x C moments are then the cheap
+    side), a ReLU behind the sum, batch statistics, and only the slots it implements."""
+    return (EXPAND_FOLD and training and relu and residual is not None and plan.is_pointwise and plan.cout > plan.cin
+            and links.input_grad is None and links.output_mask is None and links.input_grad_out is None)
+
+
+
 class _ConvBnActPoolFn(Function):
     """conv -> batch-norm -> ReLU -> max-pool; the full-resolution activation is never stored."""
 
@@ -488,6 +605,9 @@ def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, e
     links = links if links is not None else _NO_LINKS
     if links.input_grad is not None and (plan.dgrad_needs_zero or not x.requires_grad):
         raise ValueError("input_grad needs an input that requires grad and a dgrad that writes every pixel")
+    if _expand_fold_ok(plan, x, residual, relu, training, links):
+        return _ExpandBnResFn.apply(x, weight, gamma, beta, residual.contiguous(), plan, run_mean, run_var, eps,
+                                    momentum, (weight, gamma, beta), links)
     return _ConvBnActFn.apply(x, weight, gamma, beta, residual, plan, run_mean, run_var, eps, momentum, relu,
                               training, (weight, gamma, beta), links)
 

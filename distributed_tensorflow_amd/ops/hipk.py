@@ -34,7 +34,15 @@ class ConvArgs(C.Structure):
         ("cin_magic", C.c_uint), ("relu", c_int), ("dense_out", c_int), ("pointwise", c_int),
         ("bn_y", c_void), ("bn_mean", c_void), ("bn_invstd", c_void), ("bn_scale", c_void), ("bn_shift", c_void),
         ("bn_mask", c_void), ("bn_relu", c_int),
-        ("ldo", c_int), ("oscale", c_void),
+        ("ldo", c_int), ("oscale", c_void), ("omask", c_void), ("dbias", c_void), ("bn_gate_store", c_int),
+        ("x2", c_void), ("K1", c_int),
+    ]
+
+
+class ProArgs(C.Structure):
+    _fields_ = [
+        ("src2", c_void), ("gate", c_void), ("c0", c_void), ("c1", c_void), ("c2", c_void), ("gscale", c_void),
+        ("gshift", c_void), ("side", c_void), ("side_mask", c_void), ("relu", c_int),
     ]
 
 
@@ -76,6 +84,7 @@ def lib():
 
 class _Sigs:
     dtfa_conv_igemm = [C.POINTER(ConvArgs), c_int, c_int, c_int, c_int, c_void]
+    dtfa_conv_pro = [C.POINTER(ConvArgs), C.POINTER(ProArgs), c_int, c_int, c_int, c_void]
     dtfa_conv_stats_rows = [c_int, c_int]
     dtfa_conv_wgrad = [C.POINTER(WgradArgs), c_int, c_int, c_int, c_int, c_void]
     dtfa_wgrad_reduce = [c_void, c_int, c_ll, c_void, c_void, c_int, c_void]

@@ -125,21 +125,7 @@ def bn_apply(y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bo
     return (z, mask) if want_mask else z
 
 
-def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, dgamma_out=None, dbeta_out=None,
-                accumulate=False, scale=None, shift=None, mask=None, partials=None):
-    """Returns (dy, dres or None, dgamma, dbeta).
-
-    ``partials`` ([R,2,C] sums of g and g*xhat, e.g. emitted by the data-gradient kernel that produced
-    ``dz``) replaces the reduction pass over ``dz`` / ``y``.
-
-    ``mask`` (uint8, one bit per element) gates ``dz`` -- the stored sign of a ReLU output, this layer's
-    own or that of the activation this layer's output was added into -- and takes precedence over
-    ``relu`` / ``zout``.
-
-    With ``relu`` the activation mask is taken from ``zout`` (the stored
-    activation output) when it is given, otherwise it is recomputed from
-    ``y*scale + shift > 0`` (valid when no residual was added), which saves
-    reading one full tensor in each of the two passes."""
+def _bn_bwd_mode(dz, y, zout, relu, scale, shift, mask):
     hipk.require(dz, BF16, "dz")
     hipk.require(y, BF16, "y")
     if dz.shape != y.shape:
@@ -159,11 +145,21 @@ def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, d
             if scale is None or shift is None:
                 raise ValueError("ReLU mask needs either zout or scale/shift")
             mode = 2
-    M, Cc = _as2d(y)
-    L = hipk.lib()
     zp = hipk.ptr(zout) if mode == 1 else (mask.data_ptr() if mode == 3 else None)
     sp = scale.data_ptr() if mode == 2 else None
     hp = shift.data_ptr() if mode == 2 else None
+    return mode, zp, sp, hp
+
+
+def bn_backward_coefs(dz, y, mean, invstd, gamma, relu: bool = False, zout=None, dgamma_out=None, dbeta_out=None,
+                      accumulate=False, scale=None, shift=None, mask=None, partials=None):
+    """First half of the batch-norm backward: the per-channel reductions (``partials`` if a producer kernel
+    already emitted them, else a pass over ``dz`` / ``y``), then ``dgamma``, ``dbeta`` and the three coefficient
+    rows of the elementwise half ``dy = coef[0]*g + coef[1]*y + coef[2]`` (``g`` = gated ``dz``).
+    Returns ``(coef [3, C], dgamma, dbeta)``; gating arguments as in :func:`bn_backward`."""
+    mode, zp, sp, hp = _bn_bwd_mode(dz, y, zout, relu, scale, shift, mask)
+    M, Cc = _as2d(y)
+    L = hipk.lib()
     if partials is not None:
         if partials.dim() != 3 or partials.shape[1] != 2 or partials.shape[2] != Cc or partials.dtype != F32:
             raise ValueError("bad batch-norm backward partials")
@@ -187,11 +183,42 @@ def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, d
                                       mean.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                       coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), acc,
                                       hipk.stream()), "bn_bwd_finalize")
+    return coef, dgamma, dbeta
+
+
+def bn_backward_apply(dz, y, coef, relu: bool = False, zout=None, want_dres: bool = False, scale=None, shift=None,
+                      mask=None):
+    """Second half: ``dy = coef[0]*g + coef[1]*y + coef[2]`` (and ``dres = g`` on request)."""
+    mode, zp, sp, hp = _bn_bwd_mode(dz, y, zout, relu, scale, shift, mask)
+    M, Cc = _as2d(y)
+    if coef.shape != (3, Cc) or coef.dtype != F32 or not coef.is_contiguous():
+        raise ValueError("bad batch-norm backward coefficients")
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
-    hipk.check(L.dtfa_bn_bwd_apply(dz.data_ptr(), y.data_ptr(), zp, dy.data_ptr(), hipk.ptr(dres),
-                                   coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), sp, hp, M, Cc, mode,
-                                   hipk.stream()), "bn_bwd_apply")
+    hipk.check(hipk.lib().dtfa_bn_bwd_apply(dz.data_ptr(), y.data_ptr(), zp, dy.data_ptr(), hipk.ptr(dres),
+                                            coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), sp, hp, M, Cc,
+                                            mode, hipk.stream()), "bn_bwd_apply")
+    return dy, dres
+
+
+def bn_backward(dz, y, zout, mean, invstd, gamma, relu: bool, want_dres: bool, dgamma_out=None, dbeta_out=None,
+                accumulate=False, scale=None, shift=None, mask=None, partials=None):
+    """Returns (dy, dres or None, dgamma, dbeta).
+
+    ``partials`` ([R,2,C] sums of g and g*xhat, e.g. emitted by the data-gradient kernel that produced
+    ``dz``) replaces the reduction pass over ``dz`` / ``y``.
+
+    ``mask`` (uint8, one bit per element) gates ``dz`` -- the stored sign of a ReLU output, this layer's
+    own or that of the activation this layer's output was added into -- and takes precedence over
+    ``relu`` / ``zout``.
+
+    With ``relu`` the activation mask is taken from ``zout`` (the stored
+    activation output) when it is given, otherwise it is recomputed from
+    ``y*scale + shift > 0`` (valid when no residual was added), which saves
+    reading one full tensor in each of the two passes."""
+    coef, dgamma, dbeta = bn_backward_coefs(dz, y, mean, invstd, gamma, relu, zout, dgamma_out, dbeta_out, accumulate,
+                                            scale, shift, mask, partials)
+    dy, dres = bn_backward_apply(dz, y, coef, relu, zout, want_dres, scale, shift, mask)
     return dy, dres, dgamma, dbeta
 
 
