@@ -83,9 +83,78 @@ __device__ __forceinline__ bf16x8 epi_load(const bf16x8* p) {
 #endif
 }
 
+// Readback geometry of the epilogue for a BM x BN tile computed by 2 x 2 waves (see conv_epilogue).
+template <int BM, int BN>
+struct EpiGeom {
+  static constexpr int WM = BM / 2, WN = BN / 2;
+  static constexpr int CHUNKS = WN / 8;      // 16-byte chunks per row
+  static constexpr int CPR = CHUNKS <= 4 ? 4 : (CHUNKS <= 8 ? 8 : 16);
+  static constexpr int RPP = 64 / CPR;       // rows per pass
+  static constexpr int NP = WM / RPP;        // passes
+  static constexpr int G = NP >= 4 ? 4 : NP; // passes whose global loads are in flight together
+};
+
+// Element offset of the 16-byte chunk a lane handles in readback pass ``pass`` (``ok`` false: nothing to do);
+// ``pixel`` receives the physical output pixel.
+template <int BM, int BN>
+__device__ __forceinline__ size_t epi_out_offset(const ConvArgs& p, int ldo, int w4, int lane, int m0, int n0, int pass,
+                                                 bool& ok, size_t& pixel) {
+  using E = EpiGeom<BM, BN>;
+  const int wr = w4 >> 1, wc = w4 & 1;
+  const int chunk_co = n0 + wc * E::WN + (lane % E::CPR) * 8;
+  const int m = m0 + wr * E::WM + pass * E::RPP + lane / E::CPR;
+  ok = m < p.M && chunk_co < p.Cout && (lane % E::CPR) < E::CHUNKS;
+  size_t opixel = 0;
+  if (ok) {
+    if (p.dense_out) {
+      opixel = (size_t)m;
+    } else {
+      const int opix = p.OYn * p.OXn;
+      int b = m / opix;
+      int rem = m - b * opix;
+      int oy = rem / p.OXn;
+      int ox = rem - oy * p.OXn;
+      opixel = ((size_t)b * p.OH + (oy * p.osy + p.oy0)) * p.OW + (ox * p.osx + p.ox0);
+    }
+  }
+  pixel = opixel;
+  return opixel * ldo + chunk_co;
+}
+
+// The epilogue's operand loads of the first G readback passes (residual / residual gradient and the gate bits).  They do not depend on the GEMM, so a kernel whose reduction is short (a 1x1
+// layer with few input channels is two k-tiles) issues them before its main loop: the tile then pays the
+// memory latency once, not once for the operand tiles and again for the epilogue.
+template <int BM, int BN>
+struct EpiPrefetch {
+  static constexpr int G = EpiGeom<BM, BN>::G;
+  bf16x8 addv[G];
+  unsigned addm[G], bnm[G];
+};
+
 template <int BM, int BN, int EPI>
+__device__ __forceinline__ void epi_prefetch(const ConvArgs& p, EpiPrefetch<BM, BN>& r, int w4, int lane, int m0, int n0) {
+  using E = EpiGeom<BM, BN>;
+  if (EPI == 1) return;
+  const int ldo = EPI == 2 ? p.ldo : p.Cout;
+  const int chunk_co = n0 + (w4 & 1) * E::WN + (lane % E::CPR) * 8;
+#pragma unroll
+  for (int i = 0; i < E::G; ++i) {
+    bool ok;
+    size_t pixel;
+    const size_t o = epi_out_offset<BM, BN>(p, ldo, w4, lane, m0, n0, i, ok, pixel);
+    const size_t off = ok ? (EPI == 2 ? pixel * p.Cout + chunk_co : o) : 0;  // idle lanes read an in-range dummy
+    if (p.addend != nullptr) {
+      r.addv[i] = epi_load((const bf16x8*)(p.addend + off));
+      r.addm[i] = (EPI != 2 && p.addend_mask != nullptr) ? (unsigned)p.addend_mask[off >> 3] : 0xffu;
+    }
+    if (EPI == 3) r.bnm[i] = p.bn_relu == 3 ? (unsigned)p.bn_mask[off >> 3] : 0xffu;
+  }
+}
+
+template <int BM, int BN, int EPI, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[BM / 64][BN / 64], char* lds_tiles,
-                                              int w4, int lane, int m0, int n0, unsigned tile_m, bool valid) {
+                                              int w4, int lane, int m0, int n0, unsigned tile_m, bool valid,
+                                              const EpiPrefetch<BM, BN>* pre = nullptr) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int EP_PITCH = WN * 2 + 16;
@@ -107,22 +176,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
   const int chunk_co = n0 + wc * WN + (lane % CPR) * 8;
   size_t last_pixel = 0;  // physical output pixel of the latest out_offset() call
   auto out_offset = [&](int pass, bool& ok) -> size_t {
-    const int m = m0 + wr * WM + pass * RPP + lane / CPR;
-    ok = m < p.M && chunk_co < p.Cout && chunk_live;
-    size_t opixel = 0;
-    if (ok) {
-      if (p.dense_out) {
-        opixel = (size_t)m;
-      } else {
-        int b = m / opix;
-        int rem = m - b * opix;
-        int oy = rem / p.OXn;
-        int ox = rem - oy * p.OXn;
-        opixel = ((size_t)b * p.OH + (oy * p.osy + p.oy0)) * p.OW + (ox * p.osx + p.ox0);
-      }
-    }
-    last_pixel = opixel;
-    return opixel * ldo + chunk_co;
+    return epi_out_offset<BM, BN>(p, ldo, w4, lane, m0, n0, pass, ok, last_pixel);
   };
   char* ep = lds_tiles + wid * (WM * EP_PITCH);
   float* xch = (float*)(lds_tiles + 4 * WM * EP_PITCH);  // [2 wave columns][WN][2] exchange area behind the row tiles
@@ -193,30 +247,43 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
     }
   }
   if (EPI == 1 || EPI == 2) {
-    // forward: plain coalesced row stores
+    // forward: coalesced row stores; a residual (EPI 2) is fetched for a group of passes at a time, all loads
+    // of a group requested before any is consumed
+    constexpr int G = EpiGeom<BM, BN>::G;
+    const bool has_res = EPI == 2 && p.addend != nullptr;
 #pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-      bool ok;
-      const size_t off = out_offset(pass, ok);
-      if (ok) {
-        const int r = pass * RPP + lane / CPR;
-        bf16x8 v = *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16);
-        if (EPI == 2 && p.addend != nullptr) {
+    for (int g0 = 0; g0 < NP; g0 += G) {
+      size_t ooff[G];
+      bool ook[G];
+      bf16x8 resv[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        ooff[i] = out_offset(g0 + i, ook[i]);
+        if (has_res) {
           // residual block: act(conv * scale + shift + residual); the residual is dense ([.., Cout])
-          const bf16x8 res = epi_load((const bf16x8*)(p.addend + last_pixel * p.Cout + chunk_co));
+          if (PRE && g0 == 0) resv[i] = pre->addv[i];
+          else resv[i] = epi_load((const bf16x8*)(p.addend + (ook[i] ? last_pixel * p.Cout + chunk_co : 0)));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        if (!ook[i]) continue;
+        const int r = (g0 + i) * RPP + lane / CPR;
+        bf16x8 v = *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16);
+        if (has_res) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            float f = (float)v[j] + (float)res[j];
+            float f = (float)v[j] + (float)resv[i][j];
             v[j] = (bf16)(p.relu ? fmaxf(f, 0.f) : f);
           }
         }
-        out_store((bf16x8*)(p.y + off), v);
+        out_store((bf16x8*)(p.y + ooff[i]), v);
         if (EPI == 2 && p.omask != nullptr) {
           // sign bits of the activation (training: all the backward pass needs of it); dense outputs only
           unsigned bits = 0;
 #pragma unroll
           for (int j = 0; j < 8; ++j) bits |= ((float)v[j] > 0.f ? 1u : 0u) << j;
-          p.omask[off >> 3] = (unsigned char)bits;
+          p.omask[ooff[i] >> 3] = (unsigned char)bits;
         }
       }
     }
@@ -224,7 +291,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
     // data gradient: the readback may add a residual gradient (optionally gated by a bitmask) and fold
     // the batch-norm backward sums.  Passes are handled in groups: all global loads of a group are
     // requested before any is consumed, so a tile pays the memory latency once per group, not per pass.
-    constexpr int G = NP >= 4 ? 4 : NP;
+    constexpr int G = EpiGeom<BM, BN>::G;
     const bool has_add = p.addend != nullptr;
     const bool has_addm = p.addend_mask != nullptr;
     const bool has_bny = EPI == 3 && p.bn_y != nullptr;
@@ -239,6 +306,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
       for (int i = 0; i < G; ++i) {
         ooff[i] = out_offset(g0 + i, ook[i]);
         const size_t off = ook[i] ? ooff[i] : 0;  // idle lanes read an in-range dummy
+        if (PRE && g0 == 0) {
+          if (has_add) { addv[i] = pre->addv[i]; addm[i] = pre->addm[i]; }
+          if (EPI == 3) {
+            if (has_bny) bnyv[i] = epi_load((const bf16x8*)(p.bn_y + off));
+            bnm[i] = pre->bnm[i];
+          }
+          continue;
+        }
         if (has_add) {
           addv[i] = epi_load((const bf16x8*)(p.addend + off));
           addm[i] = has_addm ? (unsigned)p.addend_mask[off >> 3] : 0xffu;

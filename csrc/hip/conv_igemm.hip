@@ -195,6 +195,11 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
       for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
 
   const int KT = (p.K + BK - 1) / BK;
+  // epilogue operands of the first readback passes, requested ahead of the main loop (narrow tiles only: the
+  // registers come on top of the accumulators)
+  constexpr bool PRE = WG == 1 && BN <= 128 && BK == 32 && EPI != 1;
+  EpiPrefetch<BM, BN> pre;
+  if (PRE && valid) epi_prefetch<BM, BN, EPI>(p, pre, wid, lane, m0, n0);
   constexpr int LPS = NA + NBW;  // LDS-DMA loads per thread and stage
   static_assert(KS % 2 == 0, "fragment double-buffering assumes an even number of k-steps per tile");
   // NST LDS stages (2 or 3): while k-tile kt is multiplied, the tiles up to kt+NST-1 are in flight.
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
   }
 #endif
   // each group stages its output through its own part of the (now idle) tile area
-  conv_epilogue<BM, BN, EPI>(p, acc, lds_tiles + grp * EP, wid, lane, m0, n0, tile_m, valid);
+  conv_epilogue<BM, BN, EPI, PRE>(p, acc, lds_tiles + grp * EP, wid, lane, m0, n0, tile_m, valid, &pre);
 }
 
 template <int BM, int BN, int BK, int EPI, int NST, int WG>
