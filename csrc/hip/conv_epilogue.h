@@ -246,106 +246,109 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
       bsh[j] = (ok && p.bn_relu == 2) ? p.bn_shift[chunk_co + j] : 0.f;
     }
   }
-  if (EPI == 1 || EPI == 2) {
-    // forward: coalesced row stores; a residual (EPI 2) is fetched for a group of passes at a time, all loads
-    // of a group requested before any is consumed
+  // Readback in groups of G passes.  All global loads of a group (residual / residual gradient, gate bits, the
+  // batch-norm input of a tap) are requested before any is consumed, and the loads of group g+1 are requested
+  // before group g is consumed (two register sets; the accumulators are dead by now), so a tile pays the memory
+  // latency of its epilogue operands once.  Group 0 may have been requested ahead of the main loop (PRE).
+  {
     constexpr int G = EpiGeom<BM, BN>::G;
-    const bool has_res = EPI == 2 && p.addend != nullptr;
-#pragma unroll
-    for (int g0 = 0; g0 < NP; g0 += G) {
-      size_t ooff[G];
-      bool ook[G];
-      bf16x8 resv[G];
-#pragma unroll
-      for (int i = 0; i < G; ++i) {
-        ooff[i] = out_offset(g0 + i, ook[i]);
-        if (has_res) {
-          // residual block: act(conv * scale + shift + residual); the residual is dense ([.., Cout])
-          if (PRE && g0 == 0) resv[i] = pre->addv[i];
-          else resv[i] = epi_load((const bf16x8*)(p.addend + (ook[i] ? last_pixel * p.Cout + chunk_co : 0)));
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < G; ++i) {
-        if (!ook[i]) continue;
-        const int r = (g0 + i) * RPP + lane / CPR;
-        bf16x8 v = *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16);
-        if (has_res) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float f = (float)v[j] + (float)resv[i][j];
-            v[j] = (bf16)(p.relu ? fmaxf(f, 0.f) : f);
-          }
-        }
-        out_store((bf16x8*)(p.y + ooff[i]), v);
-        if (EPI == 2 && p.omask != nullptr) {
-          // sign bits of the activation (training: all the backward pass needs of it); dense outputs only
-          unsigned bits = 0;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) bits |= ((float)v[j] > 0.f ? 1u : 0u) << j;
-          p.omask[ooff[i] >> 3] = (unsigned char)bits;
-        }
-      }
-    }
-  } else {
-    // data gradient: the readback may add a residual gradient (optionally gated by a bitmask) and fold
-    // the batch-norm backward sums.  Passes are handled in groups: all global loads of a group are
-    // requested before any is consumed, so a tile pays the memory latency once per group, not per pass.
-    constexpr int G = EpiGeom<BM, BN>::G;
-    const bool has_add = p.addend != nullptr;
-    const bool has_addm = p.addend_mask != nullptr;
+    constexpr int NG = NP / G;
+    static_assert(NP % G == 0, "passes are grouped evenly");
+    const bool has_add = EPI != 1 && p.addend != nullptr;
+    const bool has_addm = (EPI == 0 || EPI == 3) && p.addend_mask != nullptr;
     const bool has_bny = EPI == 3 && p.bn_y != nullptr;
     const bool gate_store = EPI == 3 && p.bn_gate_store != 0;
-#pragma unroll
-    for (int g0 = 0; g0 < NP; g0 += G) {
+    struct Group {
       size_t ooff[G];
       bool ook[G];
       bf16x8 addv[G], bnyv[G];
       unsigned addm[G], bnm[G];
+    };
+    Group grp[2];
+    auto load_group = [&](int g0, Group& q, bool from_pre) {
 #pragma unroll
       for (int i = 0; i < G; ++i) {
-        ooff[i] = out_offset(g0 + i, ook[i]);
-        const size_t off = ook[i] ? ooff[i] : 0;  // idle lanes read an in-range dummy
-        if (PRE && g0 == 0) {
-          if (has_add) { addv[i] = pre->addv[i]; addm[i] = pre->addm[i]; }
-          if (EPI == 3) {
-            if (has_bny) bnyv[i] = epi_load((const bf16x8*)(p.bn_y + off));
-            bnm[i] = pre->bnm[i];
-          }
-          continue;
-        }
+        q.ooff[i] = out_offset(g0 + i, q.ook[i]);
+        // idle lanes read an in-range dummy; the forward residual is dense ([.., Cout]) even when y is a slice
+        const size_t off = q.ook[i] ? (EPI == 2 ? last_pixel * p.Cout + chunk_co : q.ooff[i]) : 0;
         if (has_add) {
-          addv[i] = epi_load((const bf16x8*)(p.addend + off));
-          addm[i] = has_addm ? (unsigned)p.addend_mask[off >> 3] : 0xffu;
+          if (from_pre) {
+            q.addv[i] = pre->addv[i];
+            q.addm[i] = pre->addm[i];
+          } else {
+            q.addv[i] = epi_load((const bf16x8*)(p.addend + off));
+            q.addm[i] = has_addm ? (unsigned)p.addend_mask[off >> 3] : 0xffu;
+          }
         }
         if (EPI == 3) {
-          if (has_bny) bnyv[i] = epi_load((const bf16x8*)(p.bn_y + off));
-          bnm[i] = p.bn_relu == 3 ? (unsigned)p.bn_mask[off >> 3] : 0xffu;
+          if (has_bny) q.bnyv[i] = epi_load((const bf16x8*)(p.bn_y + off));
+          q.bnm[i] = from_pre ? pre->bnm[i] : (p.bn_relu == 3 ? (unsigned)p.bn_mask[off >> 3] : 0xffu);
         }
       }
+    };
+    auto consume_group = [&](int g0, const Group& q) {
 #pragma unroll
       for (int i = 0; i < G; ++i) {
-        if (!ook[i]) continue;
+        if (!q.ook[i]) continue;
         const int r = (g0 + i) * RPP + lane / CPR;
         bf16x8 v = *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16);
-        if (has_add) {
+        if (EPI == 1 || EPI == 2) {
+          if (has_add) {
+            // residual block: act(conv * scale + shift + residual)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (((addm[i] >> j) & 1u) ? (float)addv[i][j] : 0.f));
-        }
-        if (!gate_store) out_store((bf16x8*)(p.y + ooff[i]), v);
-        if (EPI == 3) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float yf = has_bny ? (float)bnyv[i][j] : 0.f;
-            float g = (float)v[j];  // the rounded value, the one the elementwise backward pass will read
-            if (has_bny && p.bn_relu == 2 && !(yf * bsc[j] + bsh[j] > 0.f)) g = 0.f;
-            if (!((bnm[i] >> j) & 1u)) g = 0.f;
-            bs1[j] += g;
-            bs2[j] += g * ((yf - bmu[j]) * bis[j]);
-            if (gate_store) v[j] = (bf16)g;
+            for (int j = 0; j < 8; ++j) {
+              float f = (float)v[j] + (float)q.addv[i][j];
+              v[j] = (bf16)(p.relu ? fmaxf(f, 0.f) : f);
+            }
           }
-          if (gate_store) out_store((bf16x8*)(p.y + ooff[i]), v);
+          out_store((bf16x8*)(p.y + q.ooff[i]), v);
+          if (EPI == 2 && p.omask != nullptr) {
+            // sign bits of the activation (training: all the backward pass needs of it); dense outputs only
+            unsigned bits = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bits |= ((float)v[j] > 0.f ? 1u : 0u) << j;
+            p.omask[q.ooff[i] >> 3] = (unsigned char)bits;
+          }
+        } else {
+          // data gradient: add a residual gradient (optionally gated by a bitmask), fold the batch-norm sums
+          if (has_add) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              v[j] = (bf16)((float)v[j] + (((q.addm[i] >> j) & 1u) ? (float)q.addv[i][j] : 0.f));
+          }
+          if (!gate_store) out_store((bf16x8*)(p.y + q.ooff[i]), v);
+          if (EPI == 3) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float yf = has_bny ? (float)q.bnyv[i][j] : 0.f;
+              float g = (float)v[j];  // the rounded value, the one the elementwise backward pass will read
+              if (has_bny && p.bn_relu == 2 && !(yf * bsc[j] + bsh[j] > 0.f)) g = 0.f;
+              if (!((q.bnm[i] >> j) & 1u)) g = 0.f;
+              bs1[j] += g;
+              if (has_bny) bs2[j] += g * ((yf - bmu[j]) * bis[j]);
+              if (gate_store) v[j] = (bf16)g;
+            }
+            if (gate_store) out_store((bf16x8*)(p.y + q.ooff[i]), v);
+          }
         }
+      }
+    };
+#ifndef EPI_PIPE
+#define EPI_PIPE 1
+#endif
+    constexpr bool PIPE = EPI_PIPE == 2 || (EPI_PIPE == 1 && EPI == 2);
+    if (PIPE) {
+      load_group(0, grp[0], PRE);
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) load_group((gi + 1) * G, grp[(gi + 1) & 1], false);
+        consume_group(gi * G, grp[gi & 1]);
+      }
+    } else {
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        load_group(gi * G, grp[0], PRE && gi == 0);
+        consume_group(gi * G, grp[0]);
       }
     }
   }

@@ -53,9 +53,15 @@ class Bottleneck(nn.Module):
             # projection block: the shortcut gates its incoming gradient with conv3's sign bits and hands
             # its input gradient to conv1's dgrad epilogue.  It is called after conv2 so that its backward
             # runs before conv1's (autograd runs later-created nodes first).
-            sign = F.GradSlot()
             h = self.conv1(x, links=F.Links(input_grad=to_conv1, input_tap=in_tap, output_tap=tap1))
             h = self.conv2(h, links=F.Links(input_tap=tap1, output_tap=tap2))
+            if F.expand_dual_ok(self.conv3, self.shortcut, h, x, self.training):
+                # both batch-norms folded through their 1x1 convolutions, one GEMM over [h | x at the stride]
+                for m in (self.conv3, self.shortcut):
+                    m._coeff_cache = None
+                return F.expand_dual(h, self.conv3, x, self.shortcut,
+                                     links=F.Links(input_tap=tap2, output_tap=out_tap, input_grad_out=to_conv1))
+            sign = F.GradSlot()
             identity = self.shortcut(x, links=F.Links(output_mask=sign, input_grad_out=to_conv1))
             return self.conv3(h, residual=identity, links=F.Links(residual_mask=sign, input_tap=tap2,
                                                                   output_tap=out_tap))

@@ -272,8 +272,11 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[torch.Tensor] = None,
              relu: bool = False, want_stats: bool = False, scale: Optional[torch.Tensor] = None,
              out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-             mask_out: Optional[torch.Tensor] = None):
+             mask_out: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None):
     """x [B,IH,IW,Cin] bf16, w [Cout,KH,KW,Cin] bf16 -> (y [B,OH,OW,Cout] bf16, stats partials or None).
+
+    Pointwise layers: with ``x2`` ([B,OH,OW,C2] bf16) the reduction runs over ``[x | x2]`` and ``w`` is
+    ``[Cout, Cin + C2]`` (two 1x1 convolutions summed in one GEMM).
 
     ``mask_out`` (uint8 [numel / 8], with ``relu`` and a dense output) receives the sign of the activation, one
     bit per element: what a training step keeps of a ReLU output for its backward pass.
@@ -287,7 +290,13 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
     B = x.shape[0]
     if tuple(x.shape[1:]) != (plan.ih, plan.iw, plan.cin):
         raise ValueError("input shape %s does not match plan (%d,%d,%d)" % (tuple(x.shape), plan.ih, plan.iw, plan.cin))
-    if w.numel() != plan.cout * plan.K or w.shape[0] != plan.cout:
+    c2 = 0
+    if x2 is not None:
+        hipk.require(x2, torch.bfloat16, "x2")
+        c2 = x2.shape[-1]
+        if not plan.is_pointwise or tuple(x2.shape[:-1]) != (B, plan.oh, plan.ow) or c2 % 8:
+            raise ValueError("a second operand needs a pointwise layer and the output's pixel grid")
+    if w.numel() != plan.cout * (plan.K + c2) or w.shape[0] != plan.cout:
         raise ValueError("weight shape %s does not match plan" % (tuple(w.shape),))
     if bias is not None:
         hipk.require(bias, torch.float32, "bias")
@@ -321,7 +330,7 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
             raise ValueError("mask_out needs a ReLU, a dense output and numel / 8 bytes")
     part = _launch_igemm(x, w, y, plan.fwd_taps, plan.T, plan.ih, plan.iw, plan.cin, plan.oh, plan.ow, plan.cout,
                          plan.oh, plan.ow, 1, 1, 0, 0, plan.sy, plan.sx, B, plan.cin_magic, bias, relu, want_stats,
-                         addend=residual, zero_taps=plan.is_pointwise, oscale=scale, ldo=ldo, omask=mask_out)
+                         addend=residual, zero_taps=plan.is_pointwise, oscale=scale, ldo=ldo, omask=mask_out, x2=x2)
     return y, part
 
 

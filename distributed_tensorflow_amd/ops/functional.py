@@ -388,26 +388,80 @@ def _col_sums(x: torch.Tensor) -> torch.Tensor:
     return K.reduce_partials(K.bn_stats_partials(x), max_rows=64, direct_rows=0)[:, 0, :].sum(0)
 
 
+def _fold_stats(x, weight, gamma, beta, run_mean, run_var, eps, momentum):
+    """Batch statistics of ``y = x W^T`` from the moments of ``x``: (W32, T = W S, s, mean, invstd, scale, shift);
+    updates the running statistics."""
+    N, C = weight.shape[0], x.shape[-1]
+    M = x.numel() // C
+    gplan = cv.get_plan(x.shape[1], x.shape[2], C, C, 1, 1, 1, 1, (0, 0, 0, 0), x.device)
+    S = torch.empty((C, C), dtype=F32, device=x.device)
+    cv.conv_wgrad(x, x, gplan, out=S)
+    s = _col_sums(x)
+    W32 = weight.reshape(N, C).float()
+    T = W32 @ S
+    mean = (W32 @ s) / M
+    var = ((T * W32).sum(1) / M - mean * mean).clamp_min_(0.0)
+    invstd = torch.rsqrt(var + eps)
+    scale = invstd * gamma if gamma is not None else invstd
+    shift = beta - mean * scale
+    if run_mean is not None:
+        run_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+        run_var.mul_(1.0 - momentum).add_(var, alpha=momentum * (M / (M - 1.0) if M > 1 else 1.0))
+    return W32, T, s, mean, invstd, scale, shift
+
+
+def _fold_backward(x, g, sum_g, plan, weight, T, s, mean, invstd, scale, want_dx):
+    """Backward of ``bn(x W^T)`` given the gradient ``g`` of its output (and ``sum_g`` = its column sums):
+    ``(dW [N, C] fp32, dgamma, wd, q)`` with ``wd`` ([C, N + C] bf16) / ``q`` ([C] fp32) the matrix and bias of the
+    data-gradient GEMM over ``[g | x]`` (None unless ``want_dx``)."""
+    N, C = plan.cout, plan.cin
+    M = x.numel() // C
+    P = torch.empty((N, C), dtype=F32, device=x.device)
+    cv.conv_wgrad(x, g, plan, out=P)
+    W32 = weight.reshape(N, C).float()
+    dgamma = invstd * ((W32 * P).sum(1) - mean * sum_g)
+    c0 = scale
+    c1 = -c0 * invstd * (dgamma / M)
+    c2 = -c0 * (sum_g / M) - c1 * mean
+    dW = (c0[:, None] * P).addcmul_(c1[:, None], T).addcmul_(c2[:, None], s[None, :])
+    wd = q = None
+    if want_dx:
+        c1W = c1[:, None] * W32
+        wd = torch.cat(((c0[:, None] * W32).t(), c1W.t() @ W32), dim=1).to(BF16).contiguous()  # [C, N + C]
+        q = W32.t() @ c2
+    return dW, dgamma, wd, q
+
+
+def _gated_gradient(dz, mask, tap):
+    """``(g, sum_m g)``: the incoming gradient gated by the sign bits -- taken as is when the kernel that produced
+    ``dz`` already stored it gated and summed it (BnBackwardTap.gate_store), else computed here."""
+    if tap is not None and tap.gated and tap.partials is not None:
+        g = dz
+        sum_g = K.reduce_partials(tap.partials, max_rows=64, direct_rows=0)[:, 0, :].sum(0)
+    else:
+        g = K.mask_mul(dz, mask)
+        sum_g = _col_sums(g)
+    if tap is not None:
+        tap.clear()
+    return g, sum_g
+
+
+def _deliver_bn_params(ctx_needs, gparam, gamma, bparam, dgamma, dbeta, ig, ib):
+    gg = gb = None
+    if gamma is not None and ctx_needs[ig]:
+        gg = _deliver_small(gparam if gparam is not None else gamma, dgamma)
+    if ctx_needs[ib]:
+        gb = _deliver_small(bparam, dbeta) if bparam is not None else dbeta
+    return gg, gb
+
+
 class _ExpandBnResFn(Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, plan, run_mean, run_var, eps, momentum, params, links):
         need_grad = any(ctx.needs_input_grad)
         N, C = plan.cout, plan.cin
         M = x.numel() // C
-        gplan = cv.get_plan(plan.ih, plan.iw, C, C, 1, 1, 1, 1, (0, 0, 0, 0), x.device)
-        S = torch.empty((C, C), dtype=F32, device=x.device)
-        cv.conv_wgrad(x, x, gplan, out=S)
-        s = _col_sums(x)
-        W32 = weight.view(N, C).float()
-        T = W32 @ S
-        mean = (W32 @ s) / M
-        var = ((T * W32).sum(1) / M - mean * mean).clamp_min_(0.0)
-        invstd = torch.rsqrt(var + eps)
-        scale = invstd * gamma if gamma is not None else invstd
-        shift = beta - mean * scale
-        if run_mean is not None:
-            run_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
-            run_var.mul_(1.0 - momentum).add_(var, alpha=momentum * (M / (M - 1.0) if M > 1 else 1.0))
+        _, T, s, mean, invstd, scale, shift = _fold_stats(x, weight, gamma, beta, run_mean, run_var, eps, momentum)
         mask = torch.empty(M * N // 8, dtype=torch.uint8, device=x.device) if need_grad else None
         z, _ = cv.conv_fwd(x, weight, plan, bias=shift, relu=True, scale=scale, residual=residual, mask_out=mask)
         ctx.plan, ctx.params, ctx.links = plan, params, links
@@ -425,51 +479,103 @@ class _ExpandBnResFn(Function):
         x, weight, mask, gamma, mean, invstd, scale, T, s = ctx.saved_tensors
         plan, links = ctx.plan, ctx.links
         wparam, gparam, bparam = ctx.params
-        N, C = plan.cout, plan.cin
-        M = x.numel() // C
-        dz = dz.contiguous()
-        tap = links.output_tap
-        if tap is not None and tap.gated and tap.partials is not None:
-            g = dz   # the producer of dz stored it gated and summed it
-            sum_g = K.reduce_partials(tap.partials, max_rows=64, direct_rows=0)[:, 0, :].sum(0)
-        else:
-            g = K.mask_mul(dz, mask)
-            sum_g = _col_sums(g)
-        if tap is not None:
-            tap.clear()
+        g, sum_g = _gated_gradient(dz.contiguous(), mask, links.output_tap)
         dres = None
         if ctx.has_res and ctx.needs_input_grad[4]:
             if links.residual_grad is not None:
                 links.residual_grad.grad, links.residual_grad.mask = g, None  # already gated: added without a mask
             else:
                 dres = g   # (a producer of the residual that waits for sign bits in ``residual_mask`` gets none)
-        P = torch.empty((N, C), dtype=F32, device=x.device)
-        cv.conv_wgrad(x, g, plan, out=P)
-        W32 = weight.view(N, C).float()
-        dbeta = sum_g
-        dgamma = invstd * ((W32 * P).sum(1) - mean * sum_g)
-        c0 = scale
-        c1 = -c0 * invstd * (dgamma / M)
-        c2 = -c0 * (sum_g / M) - c1 * mean
-        gw = gg = gb = gx = None
+        dW, dgamma, wd, q = _fold_backward(x, g, sum_g, plan, weight, T, s, mean, invstd, scale, ctx.needs_input_grad[0])
+        gw = gx = None
         if ctx.needs_input_grad[1]:
-            dW = (c0[:, None] * P).addcmul_(c1[:, None], T).addcmul_(c2[:, None], s[None, :])
             gw = _deliver_small(wparam if wparam is not None else weight, dW)
             if gw is not None:
                 gw = gw.view(weight.shape)
-        if gamma is not None and ctx.needs_input_grad[2]:
-            gg = _deliver_small(gparam if gparam is not None else gamma, dgamma)
-        if ctx.needs_input_grad[3]:
-            gb = _deliver_small(bparam, dbeta) if bparam is not None else dbeta
+        gg, gb = _deliver_bn_params(ctx.needs_input_grad, gparam, gamma, bparam, dgamma, sum_g, 2, 3)
         if ctx.needs_input_grad[0]:
-            c1W = c1[:, None] * W32
-            wd = torch.cat(((c0[:, None] * W32).t(), c1W.t() @ W32), dim=1).to(BF16).contiguous()  # [C, N + C]
-            q = W32.t() @ c2
             itap = links.input_tap
             if itap is not None and not (itap.armed and cv.dgrad_can_tap(plan)):
                 itap = None
             gx = cv.conv_dgrad(g, weight, plan, bn_tap=itap, wd=wd, x2=x, dbias=q)
         return gx, gw, gg, gb, dres, None, None, None, None, None, None, None
+
+
+class _ExpandDualFn(Function):
+    """``relu(bn(x W^T) + bn_s(x_s W_s^T))``: the tail of a projection block, both batch-norms folded through
+    their 1x1 convolutions and the two convolutions summed in ONE GEMM over ``[x | x_s]`` (``x_s`` = the block input
+    at the shortcut's stride).  Neither convolution output nor the shortcut activation exists in memory."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, xs_full, weight_s, gamma_s, beta_s, plan, stride_s, run, run_s, eps,
+                momentum, params, params_s, links):
+        need_grad = any(ctx.needs_input_grad)
+        sy, sx = stride_s
+        xs = xs_full if (sy == 1 and sx == 1) else xs_full[:, ::sy, ::sx, :].contiguous()
+        N, C, Cs = plan.cout, plan.cin, xs.shape[-1]
+        M = x.numel() // C
+        if tuple(xs.shape[:3]) != tuple(x.shape[:3]):
+            raise ValueError("shortcut input %s does not land on the block's output grid %s" % (tuple(xs.shape), tuple(x.shape)))
+        W32, T, s, mean, invstd, scale, shift = _fold_stats(x, weight, gamma, beta, run[0], run[1], eps, momentum)
+        Ws32, Ts, ss, mean_s, invstd_s, scale_s, shift_s = _fold_stats(xs, weight_s, gamma_s, beta_s, run_s[0], run_s[1],
+                                                                       eps, momentum)
+        wcat = torch.cat((scale[:, None] * W32, scale_s[:, None] * Ws32), dim=1).to(BF16).contiguous()
+        mask = torch.empty(M * N // 8, dtype=torch.uint8, device=x.device) if need_grad else None
+        z, _ = cv.conv_fwd(x, wcat, plan, bias=shift + shift_s, relu=True, x2=xs, mask_out=mask)
+        ctx.plan, ctx.params, ctx.params_s, ctx.links, ctx.stride_s = plan, params, params_s, links, (sy, sx)
+        ctx.full_shape = tuple(xs_full.shape)
+        if need_grad and links.output_tap is not None:
+            tap = links.output_tap
+            tap.clear()
+            tap.mask, tap.relu_mode, tap.gate_store = mask, 3, True
+        if need_grad:
+            ctx.save_for_backward(x, weight, gamma, mean, invstd, scale, T, s,
+                                  xs, weight_s, gamma_s, mean_s, invstd_s, scale_s, Ts, ss, mask)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (x, weight, gamma, mean, invstd, scale, T, s,
+         xs, weight_s, gamma_s, mean_s, invstd_s, scale_s, Ts, ss, mask) = ctx.saved_tensors
+        plan, links = ctx.plan, ctx.links
+        sy, sx = ctx.stride_s
+        g, sum_g = _gated_gradient(dz.contiguous(), mask, links.output_tap)
+        need = ctx.needs_input_grad
+        # main branch
+        dW, dgamma, wd, q = _fold_backward(x, g, sum_g, plan, weight, T, s, mean, invstd, scale, need[0])
+        wparam, gparam, bparam = ctx.params
+        gw = gx = gws = gxs = None
+        if need[1]:
+            gw = _deliver_small(wparam if wparam is not None else weight, dW)
+            if gw is not None:
+                gw = gw.view(weight.shape)
+        gg, gb = _deliver_bn_params(need, gparam, gamma, bparam, dgamma, sum_g, 2, 3)
+        # shortcut branch (same g)
+        Cs = xs.shape[-1]
+        plan_s = cv.get_plan(plan.ih, plan.iw, Cs, plan.cout, 1, 1, 1, 1, (0, 0, 0, 0), x.device)
+        dWs, dgamma_s, wds, qs = _fold_backward(xs, g, sum_g, plan_s, weight_s, Ts, ss, mean_s, invstd_s, scale_s, need[4])
+        wparam_s, gparam_s, bparam_s = ctx.params_s
+        if need[5]:
+            gws = _deliver_small(wparam_s if wparam_s is not None else weight_s, dWs)
+            if gws is not None:
+                gws = gws.view(weight_s.shape)
+        ggs, gbs = _deliver_bn_params(need, gparam_s, gamma_s, bparam_s, dgamma_s, sum_g, 6, 7)
+        if need[4]:
+            d = cv.conv_dgrad(g, weight_s, plan_s, wd=wds, x2=xs, dbias=qs)
+            if sy == 1 and sx == 1:
+                gxs = d
+            else:
+                gxs = torch.zeros(ctx.full_shape, dtype=BF16, device=x.device)
+                gxs[:, ::sy, ::sx, :] = d
+            slot = links.input_grad_out
+            if slot is not None and not slot.consumed:
+                slot.grad, gxs = gxs, None   # the sibling consumer of the block input adds it in its dgrad epilogue
+        if need[0]:
+            itap = links.input_tap
+            if itap is not None and not (itap.armed and cv.dgrad_can_tap(plan)):
+                itap = None
+            gx = cv.conv_dgrad(g, weight, plan, bn_tap=itap, wd=wd, x2=x, dbias=q)
+        return (gx, gw, gg, gb, gxs, gws, ggs, gbs) + (None,) * 9
 
 
 EXPAND_FOLD = os.environ.get("DTFA_EXPAND_FOLD", "1") == "1"
@@ -610,6 +716,29 @@ def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, e
                                     momentum, (weight, gamma, beta), links)
     return _ConvBnActFn.apply(x, weight, gamma, beta, residual, plan, run_mean, run_var, eps, momentum, relu,
                               training, (weight, gamma, beta), links)
+
+
+def expand_dual_ok(main, shortcut, x, x_in, training: bool) -> bool:
+    """True when the tail of a projection block (``main`` = the expanding 1x1 layer, ``shortcut`` = the strided 1x1
+    projection of the block input, both ``ConvBnAct``-like modules) can run as one folded GEMM on the device."""
+    return (EXPAND_FOLD and training and _use_hip(x) and torch.is_grad_enabled()
+            and main.weight.shape[1] == 1 and main.weight.shape[2] == 1 and main.stride == (1, 1)
+            and shortcut.weight.shape[1] == 1 and shortcut.weight.shape[2] == 1
+            and main.relu and not shortcut.relu and main.weight.shape[0] > main.weight.shape[3]
+            and main.weight.shape[0] == shortcut.weight.shape[0] and x_in.shape[-1] % 8 == 0)
+
+
+def expand_dual(x, main, x_in, shortcut, links=None):
+    """``relu(main.bn(main.conv(x)) + shortcut.bn(shortcut.conv(x_in)))`` for 1x1 layers (see ``_ExpandDualFn``).
+    ``links``: ``input_tap`` / ``output_tap`` as for ``conv_bn_act``; ``input_grad_out`` receives the gradient of
+    ``x_in`` through the shortcut (for the data-gradient epilogue of the other consumer of ``x_in``)."""
+    links = links if links is not None else _NO_LINKS
+    plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], main.weight.shape[0], 1, 1, 1, 1, (0, 0, 0, 0), x.device)
+    return _ExpandDualFn.apply(x, main.weight, main.gamma, main.beta, x_in, shortcut.weight, shortcut.gamma,
+                               shortcut.beta, plan, tuple(shortcut.stride), (main.running_mean, main.running_var),
+                               (shortcut.running_mean, shortcut.running_var), main.eps, main.momentum,
+                               (main.weight, main.gamma, main.beta), (shortcut.weight, shortcut.gamma, shortcut.beta),
+                               links)
 
 
 # ----------------------------------------------------------------------------

@@ -119,3 +119,56 @@ def test_folded_expand_in_a_block_uses_gated_gradient_handoff():
         e_fold = (a - r).pow(2).mean().sqrt().item() / rms
         e_base = (b - r).pow(2).mean().sqrt().item() / rms
         assert e_fold <= 1.25 * e_base + 1e-2, (e_fold, e_base)
+
+
+@pytest.mark.parametrize("cin,width,stride,hw", [(64, 64, 1, 14), (256, 128, 2, 14), (128, 64, 2, 9)])
+def test_folded_projection_block_matches_fp32_like_the_unfolded_kernels(cin, width, stride, hw):
+    """A projection bottleneck (strided 1x1 shortcut with its own batch-norm): conv3 and the shortcut run as one
+    folded GEMM over [h | x at the stride].  Outputs, every parameter gradient and the input gradient against fp32
+    CPU autograd, with the unfolded device kernels as the yardstick for bf16 noise."""
+    import copy
+
+    from distributed_tensorflow_amd.models.layers import cast_for_device
+    from distributed_tensorflow_amd.models.resnet import Bottleneck
+
+    torch.manual_seed(cin + stride)
+    blk = Bottleneck(cin, width, stride, "p", zero_init_residual=False)
+    with torch.no_grad():
+        for m in (blk.conv3, blk.shortcut):
+            m.gamma.uniform_(0.5, 1.5)
+            m.beta.normal_(0.0, 0.2)
+    ref_blk = copy.deepcopy(blk)
+    cast_for_device(blk, "cuda").train()
+    ref_blk.train()
+    for pc, pg in zip(ref_blk.parameters(), blk.parameters()):
+        pc.data = pg.data.float().cpu()
+    x0 = torch.relu(torch.randn(6, hw, hw, cin)).to(BF16)
+    oh = (hw - 1) // stride + 1
+    dz = torch.randn(6, oh, oh, width * 4).to(BF16)
+
+    def run(b, device, dtype, fold):
+        old = F.EXPAND_FOLD
+        F.EXPAND_FOLD = fold
+        try:
+            b.zero_grad(set_to_none=True)
+            x = x0.to(device, dtype).clone().requires_grad_(True)
+            # the block input must itself come out of an op for the slots to engage as in the network
+            out = b(x * 1.0, in_tap=None, out_tap=None)
+            out.backward(dz.to(device, dtype))
+            stats = [b.conv3.running_mean, b.conv3.running_var, b.shortcut.running_mean, b.shortcut.running_var]
+            return ([out.detach().float().cpu()] + [p.grad.detach().float().cpu() for p in b.parameters()]
+                    + [x.grad.float().cpu()] + [t.detach().float().cpu().clone() for t in stats])
+        finally:
+            F.EXPAND_FOLD = old
+
+    want = run(ref_blk, "cpu", torch.float32, False)
+    got = run(blk, "cuda", BF16, True)
+    for m in (blk.conv3, blk.shortcut):   # running statistics: start both device runs from the same state
+        m.running_mean.zero_()
+        m.running_var.fill_(1.0)
+    base = run(blk, "cuda", BF16, False)
+    for i, (r, a, b_) in enumerate(zip(want, got, base)):
+        rms = r.pow(2).mean().sqrt().item() + 1e-9
+        e_fold = (a - r).pow(2).mean().sqrt().item() / rms
+        e_base = (b_ - r).pow(2).mean().sqrt().item() / rms
+        assert e_fold <= 1.25 * e_base + 1e-2, (i, e_fold, e_base)
