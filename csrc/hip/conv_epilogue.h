@@ -3,6 +3,7 @@
 // bf16 rows staged through LDS so that global stores are 16 B per lane.
 #pragma once
 #include "common.h"
+#include "ew_pack.h"
 
 struct ConvArgs {
   const bf16* x;
@@ -246,6 +247,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
       bsh[j] = (ok && p.bn_relu == 2) ? p.bn_shift[chunk_co + j] : 0.f;
     }
   }
+  f32x2 bs1p_out[4], bs2p_out[4];
   // Readback in groups of G passes.  All global loads of a group (residual / residual gradient, gate bits, the
   // batch-norm input of a tap) are requested before any is consumed, and the loads of group g+1 are requested
   // before group g is consumed (two register sets; the accumulators are dead by now), so a tile pays the memory
@@ -286,50 +288,74 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
         }
       }
     };
+    // two bits of a gate byte -> an AND mask over the two bf16 halves of a word
+    auto keep2 = [](unsigned bits) -> unsigned { return ((bits & 1u) ? 0xffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u); };
+    f32x2 bs1p[4], bs2p[4];   // EPI 3: the sums as fp32 pairs (v_pk_add_f32 / v_pk_fma_f32)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bs1p[j] = bs2p[j] = f32x2{0.f, 0.f};
+    // Per element the readback is a handful of operations, but a 128 x 128 tile of a short-reduction layer is
+    // nothing but readback: written one element at a time it cost as much vector-ALU time as the tile's memory
+    // traffic.  Hence two elements per instruction on the packed bf16 words, gates as AND masks.
     auto consume_group = [&](int g0, const Group& q) {
 #pragma unroll
       for (int i = 0; i < G; ++i) {
         if (!q.ook[i]) continue;
         const int r = (g0 + i) * RPP + lane / CPR;
-        bf16x8 v = *(const bf16x8*)(ep + r * EP_PITCH + (lane % CPR) * 16);
+        u32x4 v = *(const u32x4*)(ep + r * EP_PITCH + (lane % CPR) * 16);
+        const u32x4 av = __builtin_bit_cast(u32x4, q.addv[i]);
         if (EPI == 1 || EPI == 2) {
+          unsigned bits = 0;
           if (has_add) {
             // residual block: act(conv * scale + shift + residual)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float f = (float)v[j] + (float)q.addv[i][j];
-              v[j] = (bf16)(p.relu ? fmaxf(f, 0.f) : f);
+            for (int j = 0; j < 4; ++j) {
+              unsigned w = pack_bf16x2(unpack_bf16x2(v[j]) + unpack_bf16x2(av[j]));
+              if (p.relu) w = relu_bf16x2(w);
+              v[j] = w;
             }
           }
-          out_store((bf16x8*)(p.y + q.ooff[i]), v);
+          out_store((bf16x8*)(p.y + q.ooff[i]), __builtin_bit_cast(bf16x8, v));
           if (EPI == 2 && p.omask != nullptr) {
-            // sign bits of the activation (training: all the backward pass needs of it); dense outputs only
-            unsigned bits = 0;
+            // sign bits of the activation (training: all the backward pass needs of it); dense outputs only.
+            // After a ReLU a value is positive exactly when its bf16 word is non-zero.
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bits |= ((float)v[j] > 0.f ? 1u : 0u) << j;
+            for (int j = 0; j < 4; ++j) bits |= positive_bits_bf16x2(v[j]) << (2 * j);
             p.omask[q.ooff[i] >> 3] = (unsigned char)bits;
           }
         } else {
           // data gradient: add a residual gradient (optionally gated by a bitmask), fold the batch-norm sums
-          if (has_add) {
+          const u32x4 yv = __builtin_bit_cast(u32x4, q.bnyv[i]);
+          u32x4 gv;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              v[j] = (bf16)((float)v[j] + (((q.addm[i] >> j) & 1u) ? (float)q.addv[i][j] : 0.f));
-          }
-          if (!gate_store) out_store((bf16x8*)(p.y + q.ooff[i]), v);
-          if (EPI == 3) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float yf = has_bny ? (float)q.bnyv[i][j] : 0.f;
-              float g = (float)v[j];  // the rounded value, the one the elementwise backward pass will read
-              if (has_bny && p.bn_relu == 2 && !(yf * bsc[j] + bsh[j] > 0.f)) g = 0.f;
-              if (!((q.bnm[i] >> j) & 1u)) g = 0.f;
-              bs1[j] += g;
-              if (has_bny) bs2[j] += g * ((yf - bmu[j]) * bis[j]);
-              if (gate_store) v[j] = (bf16)g;
+          for (int j = 0; j < 4; ++j) {
+            unsigned w = v[j];
+            if (has_add) {
+              const unsigned aw = has_addm ? (av[j] & keep2(q.addm[i] >> (2 * j))) : av[j];
+              w = pack_bf16x2(unpack_bf16x2(w) + unpack_bf16x2(aw));
             }
-            if (gate_store) out_store((bf16x8*)(p.y + q.ooff[i]), v);
+            v[j] = w;
+            if (EPI == 3) {
+              // g: the rounded value, the one the elementwise backward pass will read, gated by the ReLU sign
+              unsigned gw = w;
+              f32x2 yf = f32x2{0.f, 0.f};
+              if (has_bny) {
+                yf = unpack_bf16x2(yv[j]);
+                if (p.bn_relu == 2) {
+                  const f32x2 pre = __builtin_elementwise_fma(yf, f32x2{bsc[2 * j], bsc[2 * j + 1]}, f32x2{bsh[2 * j], bsh[2 * j + 1]});
+                  gw &= (pre.x > 0.f ? 0xffffu : 0u) | (pre.y > 0.f ? 0xffff0000u : 0u);
+                }
+              }
+              if (p.bn_relu == 3) gw &= keep2(q.bnm[i] >> (2 * j));
+              const f32x2 g = unpack_bf16x2(gw);
+              bs1p[j] += g;
+              if (has_bny) {
+                const f32x2 xh = (yf - f32x2{bmu[2 * j], bmu[2 * j + 1]}) * f32x2{bis[2 * j], bis[2 * j + 1]};
+                bs2p[j] = __builtin_elementwise_fma(g, xh, bs2p[j]);
+              }
+              gv[j] = gw;
+            }
           }
+          out_store((bf16x8*)(p.y + q.ooff[i]), __builtin_bit_cast(bf16x8, gate_store ? gv : v));
         }
       }
     };
@@ -351,8 +377,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
         consume_group(gi * G, grp[0]);
       }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bs1p_out[j] = bs1p[j];
+      bs2p_out[j] = bs2p[j];
+    }
   }
   if (EPI == 3) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bs1[2 * j] = bs1p_out[j].x;
+      bs1[2 * j + 1] = bs1p_out[j].y;
+      bs2[2 * j] = bs2p_out[j].x;
+      bs2[2 * j + 1] = bs2p_out[j].y;
+    }
     // lanes that share a chunk column differ in the lane bits above log2(CPR): fold those
 #pragma unroll
     for (int sh = CPR; sh < 64; sh <<= 1) {

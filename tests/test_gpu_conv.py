@@ -21,10 +21,10 @@ CASES = [
     (1, 35, 35, 48, 64, 5, 5, 1, 1, "SAME"),        # inception 5x5
     (4, 8, 8, 448, 384, 3, 3, 1, 1, "SAME"),
     (5, 12, 12, 32, 40, 3, 3, 2, 2, "SAME"),        # odd Cout tile tail, SAME stride 2
-    (3, 10, 12, 32, 128, 3, 3, 1, 1, "SAME"),       # halo kernel: one 32-channel chunk, tiles span images
-    (2, 28, 28, 128, 128, 3, 3, 1, 1, "SAME"),      # halo kernel: resnet 3x3, four chunks
-    (1, 57, 57, 64, 72, 3, 3, 1, 1, "SAME"),        # halo kernel: wide rows (244-pixel image), Cout tail
-    (2, 20, 20, 96, 64, 3, 1, 1, 1, "SAME"),        # halo kernel: 3 taps, narrow output tile
+    (3, 10, 12, 32, 128, 3, 3, 1, 1, "SAME"),       # one 32-channel chunk per tap, row tiles span images
+    (2, 28, 28, 128, 128, 3, 3, 1, 1, "SAME"),      # resnet 3x3, four chunks per tap
+    (1, 57, 57, 64, 72, 3, 3, 1, 1, "SAME"),        # wide rows, Cout tail
+    (2, 20, 20, 96, 64, 3, 1, 1, 1, "SAME"),        # 3 taps, narrow output tile
 ]
 
 

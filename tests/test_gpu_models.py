@@ -143,6 +143,30 @@ def test_inception_head_trains_only_head():
     assert all(l == l for l in losses)
 
 
+def test_inception_head_gradient_matches_cpu_autograd():
+    """The reference trains ``fc_trainable/*`` only (recognition_flower/single/flower_train.py:141-152): on the
+    features the frozen trunk produces in training mode, the head's loss (cross-entropy + both activity-L2 terms)
+    and the gradients of its four variables equal fp32 CPU autograd of the same head."""
+    torch.manual_seed(0)
+    model = build_model("inception_v3_head", device="cuda", head_dropout_rate=0.0).train()
+    x, y = _images(8, 299, seed=4)
+    with torch.no_grad():
+        feats = model.trunk(x.cuda().bfloat16())
+    assert feats.shape == (8, 2048) and torch.isfinite(feats.float()).all()
+    cpu_head = copy.deepcopy(model.head).float().cpu().train()
+    logits, reg = model.head(feats)
+    loss, _, _, _ = F.softmax_xent(logits, y.cuda().to(torch.int32), 5, act_l2=model.head.act_l2)
+    (loss + reg).backward()
+    logits_c, reg_c = cpu_head(feats.float().cpu())
+    loss_c, _, _, _ = F.softmax_xent(logits_c, y, 5, act_l2=cpu_head.act_l2)
+    (loss_c + reg_c).backward()
+    assert abs((loss + reg).item() - (loss_c + reg_c).item()) <= 2e-2 * abs((loss_c + reg_c).item())
+    for (n, pg), (_, pc) in zip(model.head.named_parameters(), cpu_head.named_parameters()):
+        a, b = pg.grad.float().cpu(), pc.grad
+        assert (a - b).norm().item() <= 2e-2 * b.norm().item() + 1e-6, n
+    assert all(p.grad is None for p in model.trunk.parameters())
+
+
 def test_step_graph_matches_eager():
     """A step replayed from a HIP graph is the same arithmetic as the eager step (deterministic kernels,
     no dropout in this model): parameters agree bit for bit after several steps."""
