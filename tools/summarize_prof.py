@@ -42,7 +42,7 @@ def main():
     for c, v in sorted(cats.items(), key=lambda kv: -kv[1]):
         print("| %s | %.2f | %.1f%% |" % (c, v / 1e6 / steps, 100 * v / tot))
     print("\n| kernel | calls | total ms | avg us | share |\n|---|---:|---:|---:|---:|")
-    for r in rows[:30]:
+    for r in rows[:int(sys.argv[4]) if len(sys.argv) > 4 else 30]:
         print("| `%s` | %s | %.2f | %.1f | %.1f%% |" % (r["Name"][:80].replace("|", "/"), r["Calls"],
                                                      float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
                                                      float(r["Percentage"])))
