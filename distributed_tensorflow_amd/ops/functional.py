@@ -385,7 +385,7 @@ class _ConvBnActFn(Function):
 # stored activations shrink by the N-wide y).  The gated gradient g is written directly by the data-gradient
 # kernel that produces dz (BnBackwardTap.gate_store), which also emits sum_m g.
 def _col_sums(x: torch.Tensor) -> torch.Tensor:
-    return K.reduce_partials(K.bn_stats_partials(x), max_rows=64, direct_rows=0)[:, 0, :].sum(0)
+    return K.sum_partial_rows(K.bn_stats_partials(x))[0]
 
 
 def _fold_stats(x, weight, gamma, beta, run_mean, run_var, eps, momentum):
@@ -399,37 +399,58 @@ def _fold_stats(x, weight, gamma, beta, run_mean, run_var, eps, momentum):
     s = _col_sums(x)
     W32 = weight.reshape(N, C).float()
     T = W32 @ S
-    mean = (W32 @ s) / M
-    var = ((T * W32).sum(1) / M - mean * mean).clamp_min_(0.0)
-    invstd = torch.rsqrt(var + eps)
-    scale = invstd * gamma if gamma is not None else invstd
-    shift = beta - mean * scale
-    if run_mean is not None:
-        run_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
-        run_var.mul_(1.0 - momentum).add_(var, alpha=momentum * (M / (M - 1.0) if M > 1 else 1.0))
+    mean, invstd, scale, shift = K.fold_forward(weight, T, s, gamma, beta, run_mean, run_var, M, eps, momentum)
     return W32, T, s, mean, invstd, scale, shift
 
 
-def _fold_backward(x, g, sum_g, plan, weight, T, s, mean, invstd, scale, want_dx):
-    """Backward of ``bn(x W^T)`` given the gradient ``g`` of its output (and ``sum_g`` = its column sums):
-    ``(dW [N, C] fp32, dgamma, wd, q)`` with ``wd`` ([C, N + C] bf16) / ``q`` ([C] fp32) the matrix and bias of the
-    data-gradient GEMM over ``[g | x]`` (None unless ``want_dx``)."""
+def _grad_buffer(param, wanted: bool):
+    """(fp32 flat-buffer view to write the gradient of ``param`` into, accumulate flag) or (None, False)."""
+    mg = getattr(param, "main_grad", None) if (wanted and param is not None) else None
+    if mg is not None and mg.dtype == F32 and mg.is_contiguous():
+        return mg, getattr(param, "_grad_filled", False)
+    return None, False
+
+
+def _fold_backward(needs, params, x, g, sum_g, plan, weight, W32, T, s, mean, invstd, scale, gamma):
+    """Backward of ``bn(x W^T)`` given the gradient ``g`` of its output and ``sum_g``, its column sums.
+    ``needs`` = (dx, dW, dgamma, dbeta) wanted.  Gradients of parameters that live in a flat fp32 gradient buffer are
+    written there by the kernel.  Returns ``(gw, gg, gb, wd, q)``: parameter gradients for autograd (None when
+    delivered) and the matrix ([C, N + C] bf16) / bias ([C] fp32) of the data-gradient GEMM over ``[g | x]``."""
+    need_x, need_w, need_g, need_b = needs
+    need_g = need_g and gamma is not None
     N, C = plan.cout, plan.cin
     M = x.numel() // C
+    wparam, gparam, bparam = params
     P = torch.empty((N, C), dtype=F32, device=x.device)
     cv.conv_wgrad(x, g, plan, out=P)
-    W32 = weight.reshape(N, C).float()
-    dgamma = invstd * ((W32 * P).sum(1) - mean * sum_g)
-    c0 = scale
-    c1 = -c0 * invstd * (dgamma / M)
-    c2 = -c0 * (sum_g / M) - c1 * mean
-    dW = (c0[:, None] * P).addcmul_(c1[:, None], T).addcmul_(c2[:, None], s[None, :])
-    wd = q = None
-    if want_dx:
-        c1W = c1[:, None] * W32
-        wd = torch.cat(((c0[:, None] * W32).t(), c1W.t() @ W32), dim=1).to(BF16).contiguous()  # [C, N + C]
-        q = W32.t() @ c2
-    return dW, dgamma, wd, q
+    wbuf, wacc = _grad_buffer(wparam, need_w)
+    gbuf, gacc = _grad_buffer(gparam, need_g)
+    bbuf, bacc = _grad_buffer(bparam, need_b)
+    dgamma, dbeta, dW, wd, W1, c2 = K.fold_backward(weight, P, T, s, sum_g, mean, invstd, scale, M, gbuf, bbuf, wbuf,
+                                                    gacc, bacc, wacc, want_dx=need_x)
+    gw = gg = gb = None
+    if need_w:
+        if wbuf is not None:
+            _notify(wparam)
+        else:
+            gw = _deliver_small(wparam if wparam is not None else weight, dW)
+            if gw is not None:
+                gw = gw.view(weight.shape)
+    if need_g:
+        if gbuf is not None:
+            _notify(gparam)
+        else:
+            gg = _deliver_small(gparam if gparam is not None else gamma, dgamma)
+    if need_b:
+        if bbuf is not None:
+            _notify(bparam)
+        else:
+            gb = _deliver_small(bparam, dbeta) if bparam is not None else dbeta
+    q = None
+    if need_x:
+        wd[:, N:].copy_(W32.t() @ W1)   # Q = W^T diag(c1) W (symmetric)
+        q = c2 @ W32
+    return gw, gg, gb, wd, q
 
 
 def _gated_gradient(dz, mask, tap):
@@ -437,7 +458,7 @@ def _gated_gradient(dz, mask, tap):
     ``dz`` already stored it gated and summed it (BnBackwardTap.gate_store), else computed here."""
     if tap is not None and tap.gated and tap.partials is not None:
         g = dz
-        sum_g = K.reduce_partials(tap.partials, max_rows=64, direct_rows=0)[:, 0, :].sum(0)
+        sum_g = K.sum_partial_rows(tap.partials)[0]
     else:
         g = K.mask_mul(dz, mask)
         sum_g = _col_sums(g)
@@ -446,22 +467,13 @@ def _gated_gradient(dz, mask, tap):
     return g, sum_g
 
 
-def _deliver_bn_params(ctx_needs, gparam, gamma, bparam, dgamma, dbeta, ig, ib):
-    gg = gb = None
-    if gamma is not None and ctx_needs[ig]:
-        gg = _deliver_small(gparam if gparam is not None else gamma, dgamma)
-    if ctx_needs[ib]:
-        gb = _deliver_small(bparam, dbeta) if bparam is not None else dbeta
-    return gg, gb
-
-
 class _ExpandBnResFn(Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, plan, run_mean, run_var, eps, momentum, params, links):
         need_grad = any(ctx.needs_input_grad)
         N, C = plan.cout, plan.cin
         M = x.numel() // C
-        _, T, s, mean, invstd, scale, shift = _fold_stats(x, weight, gamma, beta, run_mean, run_var, eps, momentum)
+        W32, T, s, mean, invstd, scale, shift = _fold_stats(x, weight, gamma, beta, run_mean, run_var, eps, momentum)
         mask = torch.empty(M * N // 8, dtype=torch.uint8, device=x.device) if need_grad else None
         z, _ = cv.conv_fwd(x, weight, plan, bias=shift, relu=True, scale=scale, residual=residual, mask_out=mask)
         ctx.plan, ctx.params, ctx.links = plan, params, links
@@ -471,14 +483,13 @@ class _ExpandBnResFn(Function):
             tap.clear()
             tap.mask, tap.relu_mode, tap.gate_store = mask, 3, True
         if need_grad:
-            ctx.save_for_backward(x, weight, mask, gamma, mean, invstd, scale, T, s)
+            ctx.save_for_backward(x, weight, mask, gamma, mean, invstd, scale, T, s, W32)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, weight, mask, gamma, mean, invstd, scale, T, s = ctx.saved_tensors
+        x, weight, mask, gamma, mean, invstd, scale, T, s, W32 = ctx.saved_tensors
         plan, links = ctx.plan, ctx.links
-        wparam, gparam, bparam = ctx.params
         g, sum_g = _gated_gradient(dz.contiguous(), mask, links.output_tap)
         dres = None
         if ctx.has_res and ctx.needs_input_grad[4]:
@@ -486,13 +497,9 @@ class _ExpandBnResFn(Function):
                 links.residual_grad.grad, links.residual_grad.mask = g, None  # already gated: added without a mask
             else:
                 dres = g   # (a producer of the residual that waits for sign bits in ``residual_mask`` gets none)
-        dW, dgamma, wd, q = _fold_backward(x, g, sum_g, plan, weight, T, s, mean, invstd, scale, ctx.needs_input_grad[0])
-        gw = gx = None
-        if ctx.needs_input_grad[1]:
-            gw = _deliver_small(wparam if wparam is not None else weight, dW)
-            if gw is not None:
-                gw = gw.view(weight.shape)
-        gg, gb = _deliver_bn_params(ctx.needs_input_grad, gparam, gamma, bparam, dgamma, sum_g, 2, 3)
+        gw, gg, gb, wd, q = _fold_backward(ctx.needs_input_grad[:4], ctx.params, x, g, sum_g, plan, weight, W32, T, s,
+                                           mean, invstd, scale, gamma)
+        gx = None
         if ctx.needs_input_grad[0]:
             itap = links.input_tap
             if itap is not None and not (itap.armed and cv.dgrad_can_tap(plan)):
@@ -530,36 +537,25 @@ class _ExpandDualFn(Function):
             tap.mask, tap.relu_mode, tap.gate_store = mask, 3, True
         if need_grad:
             ctx.save_for_backward(x, weight, gamma, mean, invstd, scale, T, s,
-                                  xs, weight_s, gamma_s, mean_s, invstd_s, scale_s, Ts, ss, mask)
+                                  xs, weight_s, gamma_s, mean_s, invstd_s, scale_s, Ts, ss, mask, W32, Ws32)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         (x, weight, gamma, mean, invstd, scale, T, s,
-         xs, weight_s, gamma_s, mean_s, invstd_s, scale_s, Ts, ss, mask) = ctx.saved_tensors
+         xs, weight_s, gamma_s, mean_s, invstd_s, scale_s, Ts, ss, mask, W32, Ws32) = ctx.saved_tensors
         plan, links = ctx.plan, ctx.links
         sy, sx = ctx.stride_s
         g, sum_g = _gated_gradient(dz.contiguous(), mask, links.output_tap)
         need = ctx.needs_input_grad
-        # main branch
-        dW, dgamma, wd, q = _fold_backward(x, g, sum_g, plan, weight, T, s, mean, invstd, scale, need[0])
-        wparam, gparam, bparam = ctx.params
-        gw = gx = gws = gxs = None
-        if need[1]:
-            gw = _deliver_small(wparam if wparam is not None else weight, dW)
-            if gw is not None:
-                gw = gw.view(weight.shape)
-        gg, gb = _deliver_bn_params(need, gparam, gamma, bparam, dgamma, sum_g, 2, 3)
-        # shortcut branch (same g)
+        # main branch, then the shortcut branch (same g)
+        gw, gg, gb, wd, q = _fold_backward(need[:4], ctx.params, x, g, sum_g, plan, weight, W32, T, s, mean, invstd,
+                                           scale, gamma)
         Cs = xs.shape[-1]
         plan_s = cv.get_plan(plan.ih, plan.iw, Cs, plan.cout, 1, 1, 1, 1, (0, 0, 0, 0), x.device)
-        dWs, dgamma_s, wds, qs = _fold_backward(xs, g, sum_g, plan_s, weight_s, Ts, ss, mean_s, invstd_s, scale_s, need[4])
-        wparam_s, gparam_s, bparam_s = ctx.params_s
-        if need[5]:
-            gws = _deliver_small(wparam_s if wparam_s is not None else weight_s, dWs)
-            if gws is not None:
-                gws = gws.view(weight_s.shape)
-        ggs, gbs = _deliver_bn_params(need, gparam_s, gamma_s, bparam_s, dgamma_s, sum_g, 6, 7)
+        gws, ggs, gbs, wds, qs = _fold_backward(need[4:8], ctx.params_s, xs, g, sum_g, plan_s, weight_s, Ws32, Ts, ss,
+                                                mean_s, invstd_s, scale_s, gamma_s)
+        gx = gxs = None
         if need[4]:
             d = cv.conv_dgrad(g, weight_s, plan_s, wd=wds, x2=xs, dbias=qs)
             if sy == 1 and sx == 1:

@@ -100,6 +100,10 @@ class _Sigs:
                             c_void, c_int, c_void]
     dtfa_bn_bwd_apply = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int,
                          c_void]
+    dtfa_fold_fwd = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_int,
+                     c_float, c_float, c_float, c_void]
+    dtfa_fold_bwd = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_float, c_void, c_void, c_void,
+                     c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_void]
     dtfa_relu_bwd = [c_void, c_void, c_void, c_ll, c_void]
     dtfa_add_bf16 = [c_void, c_void, c_void, c_ll, c_void]
     dtfa_bn_relu_maxpool_fwd = [c_void, c_void, c_void, c_void, c_void, C.POINTER(PoolArgs), c_int, c_void]

@@ -43,6 +43,81 @@ def reduce_partials(part: torch.Tensor, max_rows: int = 1024, direct_rows: int =
     return out
 
 
+def sum_partial_rows(part: torch.Tensor) -> torch.Tensor:
+    """[R][NV][C] -> [NV][C]: all rows summed in a fixed order (two wide passes instead of one long chain)."""
+    R, NV, Cc = part.shape
+    L = hipk.lib()
+    if R > 64:
+        mid = torch.empty((64, NV, Cc), dtype=F32, device=part.device)
+        hipk.check(L.dtfa_partial_reduce(part.data_ptr(), mid.data_ptr(), R, NV, Cc, 64, hipk.stream()), "partial_reduce")
+        part, R = mid, 64
+    out = torch.empty((1, NV, Cc), dtype=F32, device=part.device)
+    hipk.check(L.dtfa_partial_reduce(part.data_ptr(), out.data_ptr(), R, NV, Cc, 1, hipk.stream()), "partial_reduce")
+    return out[0]
+
+
+def fold_forward(weight: torch.Tensor, T: torch.Tensor, s: torch.Tensor, gamma, beta, run_mean, run_var, count: int,
+                 eps: float, momentum: float):
+    """Statistics of ``y = x W^T`` from ``T = W (x^T x)`` and ``s = x^T 1``: (mean, invstd, scale, shift), running
+    statistics updated in place (csrc/hip/fold.hip)."""
+    hipk.require(weight, BF16, "weight")
+    hipk.require(T, F32, "T")
+    hipk.require(s, F32, "s")
+    N = weight.shape[0]
+    Cc = weight.numel() // N
+    if tuple(T.shape) != (N, Cc) or s.numel() != Cc:
+        raise ValueError("fold_forward shapes")
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (run_mean, "running_mean"), (run_var, "running_var")):
+        if t is not None:
+            hipk.require(t, F32, nm)
+            if t.numel() != N:
+                raise ValueError("%s has %d elements, expected %d" % (nm, t.numel(), N))
+    out = torch.empty((4, N), dtype=F32, device=weight.device)
+    hipk.check(hipk.lib().dtfa_fold_fwd(weight.data_ptr(), T.data_ptr(), s.data_ptr(), hipk.ptr(gamma), hipk.ptr(beta),
+                                        out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                        hipk.ptr(run_mean), hipk.ptr(run_var), N, Cc, float(count), float(eps),
+                                        float(momentum), hipk.stream()), "fold_fwd")
+    return out[0], out[1], out[2], out[3]
+
+
+def fold_backward(weight, P, T, s, sum_g, mean, invstd, scale, count: int, dgamma_out=None, dbeta_out=None, dw_out=None,
+                  acc_gamma=False, acc_beta=False, acc_w=False, want_dx=True):
+    """Backward algebra of the folded batch-norm (csrc/hip/fold.hip).  Writes ``dgamma`` / ``dbeta`` / ``dW`` into the
+    given fp32 buffers (added when the ``acc_*`` flag is set) or fresh ones, and returns
+    ``(dgamma, dbeta, dW, wd, W1, c2)`` with ``wd`` [C, N + C] bf16 whose first N columns hold ``(c0 W)^T`` (the
+    rest is for ``(W^T W1)``), ``W1 = c1 W`` fp32 and ``c2`` -- the last three None unless ``want_dx``."""
+    hipk.require(weight, BF16, "weight")
+    N = weight.shape[0]
+    Cc = weight.numel() // N
+    for t, nm, shp in ((P, "P", (N, Cc)), (T, "T", (N, Cc))):
+        hipk.require(t, F32, nm)
+        if tuple(t.shape) != shp:
+            raise ValueError("fold_backward: %s shape" % nm)
+    for t, nm, n in ((s, "s", Cc), (sum_g, "sum_g", N), (mean, "mean", N), (invstd, "invstd", N), (scale, "scale", N)):
+        hipk.require(t, F32, nm)
+        if t.numel() != n:
+            raise ValueError("fold_backward: %s size" % nm)
+    dev = weight.device
+    for o, n in ((dgamma_out, N), (dbeta_out, N), (dw_out, N * Cc)):
+        if o is not None and (o.dtype != F32 or o.numel() != n or not o.is_contiguous()):
+            raise ValueError("fold_backward: bad gradient output buffer")
+    dgamma = dgamma_out if dgamma_out is not None else torch.empty(N, dtype=F32, device=dev)
+    dbeta = dbeta_out if dbeta_out is not None else torch.empty(N, dtype=F32, device=dev)
+    dW = dw_out if dw_out is not None else torch.empty((N, Cc), dtype=F32, device=dev)
+    wd = W1 = c2 = None
+    if want_dx:
+        wd = torch.empty((Cc, N + Cc), dtype=BF16, device=dev)
+        W1 = torch.empty((N, Cc), dtype=F32, device=dev)
+        c2 = torch.empty(N, dtype=F32, device=dev)
+    hipk.check(hipk.lib().dtfa_fold_bwd(weight.data_ptr(), P.data_ptr(), T.data_ptr(), s.data_ptr(), sum_g.data_ptr(),
+                                        mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), float(count),
+                                        dgamma.data_ptr(), dbeta.data_ptr(), dW.data_ptr(), hipk.ptr(wd), hipk.ptr(W1),
+                                        hipk.ptr(c2), N, Cc, N + Cc, 1 if (acc_gamma and dgamma_out is not None) else 0,
+                                        1 if (acc_beta and dbeta_out is not None) else 0,
+                                        1 if (acc_w and dw_out is not None) else 0, hipk.stream()), "fold_bwd")
+    return dgamma, dbeta, dW, wd, W1, c2
+
+
 def bn_stats_partials(x: torch.Tensor) -> torch.Tensor:
     hipk.require(x, BF16, "x")
     M, Cc = _as2d(x)
