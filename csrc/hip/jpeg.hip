@@ -1,7 +1,8 @@
 // GPU half of the JPEG decoder (gfx950).  The host entropy decoder
 // (csrc/host/jpeg_huffman.cc) delivers quantised DCT coefficients; here
 //   jpeg_idct:   dequantise + 8x8 inverse DCT + level shift -> uint8 component planes
-//   jpeg_color:  chroma upsampling (replication) + YCbCr -> RGB -> packed HWC uint8
+//   jpeg_color:  chroma upsampling (libjpeg's "fancy" triangle filters for 2:1 ratios, replication otherwise)
+//                + YCbCr -> RGB -> packed HWC uint8
 // Both kernels are batched: blockIdx.y selects the image, a descriptor table
 // carries per-image geometry, so a whole batch is two launches.
 #include "common.h"
@@ -63,8 +64,34 @@ __global__ void jpeg_color_kernel(const unsigned char* __restrict__ planes, cons
   int y = i / d.width, x = i % d.width;
   float comp[3];
   for (int c = 0; c < d.ncomp && c < 3; ++c) {
-    int cy = y * d.vs[c] / d.vmax, cx = x * d.hs[c] / d.hmax;
-    comp[c] = planes[d.plane_offset[c] + (size_t)cy * (d.blocks_w[c] * 8) + cx];
+    const unsigned char* P = planes + d.plane_offset[c];
+    const int pitch = d.blocks_w[c] * 8;
+    const int hr = d.hmax / d.hs[c], vr = d.vmax / d.vs[c];
+    const bool exact = hr * d.hs[c] == d.hmax && vr * d.vs[c] == d.vmax;
+    // real (unpadded) size of the subsampled plane: the filters replicate its last row / column, as libjpeg does
+    const int cw = (d.width * d.hs[c] + d.hmax - 1) / d.hmax, ch = (d.height * d.vs[c] + d.vmax - 1) / d.vmax;
+    int v;
+    if (exact && hr == 2 && vr == 2) {
+      // h2v2: 3/4 nearer + 1/4 further row, then the same horizontally; rounding biases 8 / 7 alternate per column
+      const int cy = y >> 1, cx = x >> 1;
+      const int yn = (y & 1) ? min(cy + 1, ch - 1) : max(cy - 1, 0);
+      const int xn = (x & 1) ? min(cx + 1, cw - 1) : max(cx - 1, 0);
+      const int here = 3 * P[(size_t)cy * pitch + cx] + P[(size_t)yn * pitch + cx];
+      const int there = 3 * P[(size_t)cy * pitch + xn] + P[(size_t)yn * pitch + xn];
+      v = (3 * here + there + ((x & 1) ? 7 : 8)) >> 4;
+    } else if (exact && hr == 2 && vr == 1) {
+      const int cx = x >> 1;
+      const int xn = (x & 1) ? min(cx + 1, cw - 1) : max(cx - 1, 0);
+      v = (3 * P[(size_t)y * pitch + cx] + P[(size_t)y * pitch + xn] + ((x & 1) ? 2 : 1)) >> 2;
+    } else if (exact && hr == 1 && vr == 2) {
+      const int cy = y >> 1;
+      const int yn = (y & 1) ? min(cy + 1, ch - 1) : max(cy - 1, 0);
+      v = (3 * P[(size_t)cy * pitch + x] + P[(size_t)yn * pitch + x] + ((y & 1) ? 2 : 1)) >> 2;
+    } else {
+      const int cy = y * d.vs[c] / d.vmax, cx = x * d.hs[c] / d.hmax;
+      v = P[(size_t)cy * pitch + cx];
+    }
+    comp[c] = (float)v;
   }
   unsigned char* o = out + d.rgb_offset + (size_t)i * 3;
   if (d.ncomp == 1) {

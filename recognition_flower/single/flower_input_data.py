@@ -22,17 +22,16 @@ from distributed_tensorflow_amd.data.preprocess import (NORM_INCEPTION, NORM_UNI
                                                         random_crop_spec, resize_on_device, resize_reference)
 
 
-def prepare_batch_on_device(flower_paths_and_classes, batch_size, device, image_size=299, max_zoom=0.2, np_rng=None):
+def prepare_batch_on_device(flower_paths_and_classes, batch_size, device, image_size=299, max_zoom=0.2, np_rng=None,
+                            cache=None):
     """GPU version of ``prepare_batch``: JPEG entropy decode on host threads,
     IDCT / colour conversion, random crop + zoom + flip and the bilinear resize
-    on the device.  Returns ``X [B, S, S, 8]`` bf16 in [-1, 1] and ``y [B]`` int32."""
+    on the device.  Returns ``X [B, S, S, 8]`` bf16 in [-1, 1] and ``y [B]`` int32.
+    ``cache`` (``data.jpeg.DecodedImageCache``) keeps decoded images on the device: a file is read and decoded the
+    first time it is drawn only."""
     np_rng = np_rng or np.random.default_rng()
     batch = sample_batch(flower_paths_and_classes, batch_size)
-    jpegs = []
-    for path, _ in batch:
-        with open(path, "rb") as f:
-            jpegs.append(f.read())
-    packed, shapes, offs = _jpeg.decode_batch_to_device(jpegs, device)
+    packed, shapes, offs = _jpeg.decode_files_to_device([p for p, _ in batch], device, cache)
     crops = [random_crop_spec(h, w, image_size, image_size, max_zoom, np_rng) for h, w, _ in shapes]
     descs = torch.from_numpy(make_descs(shapes, offs, crops)).to(device)
     X = resize_on_device(packed, descs, len(batch), (image_size, image_size), "bilinear", False, NORM_INCEPTION)
@@ -40,7 +39,7 @@ def prepare_batch_on_device(flower_paths_and_classes, batch_size, device, image_
     return X, y
 
 
-def evaluation_batches(flower_paths_and_classes, batch_size, device, image_size=299):
+def evaluation_batches(flower_paths_and_classes, batch_size, device, image_size=299, cache=None):
     """Every item once, in order, WITHOUT augmentation: the whole image resized (bilinear) to the network size,
     [-1, 1].  Yields ``(X, y)`` like the training batches (device: bf16 NHWC8; CPU: fp32 NHWC8).  This is the
     pass over the held-out 20 % that the reference splits off and never runs
@@ -51,11 +50,7 @@ def evaluation_batches(flower_paths_and_classes, batch_size, device, image_size=
         batch = items[i:i + batch_size]
         y = torch.tensor([c for _, c in batch], dtype=torch.int32, device=device)
         if device.type == "cuda":
-            jpegs = []
-            for path, _ in batch:
-                with open(path, "rb") as f:
-                    jpegs.append(f.read())
-            packed, shapes, offs = _jpeg.decode_batch_to_device(jpegs, device)
+            packed, shapes, offs = _jpeg.decode_files_to_device([p for p, _ in batch], device, cache)
             descs = torch.from_numpy(make_descs(shapes, offs, [full_crop(h, w) for h, w, _ in shapes])).to(device)
             X = resize_on_device(packed, descs, len(batch), (image_size, image_size), "bilinear", False, NORM_INCEPTION)
         else:

@@ -54,6 +54,9 @@ flags.DEFINE_string("device", "auto", "cuda | cpu | auto")
 flags.DEFINE_integer("max_steps", 0, "Stop after this many steps (0 = n_epochs * iterations per epoch).")
 flags.DEFINE_integer("seed", 42, "Random seed.")
 flags.DEFINE_boolean("prefetch", True, "GPU: prepare the next batch on a helper thread and a copy stream during the step.")
+flags.DEFINE_integer("prefetch_depth", 2, "GPU: batches prepared ahead of the step.")
+flags.DEFINE_float("image_cache_gb", 8.0, "GPU: device memory for decoded images (a file is read and entropy-decoded the "
+                   "first time it is drawn; afterwards its pixels are served from the device). 0 disables the cache.")
 flags.DEFINE_string("checkpoint_dir", "", "Also write a training checkpoint here at the end (optional).")
 flags.DEFINE_string("profile_dir", "", "Write a torch.profiler Chrome trace of a few steps here (empty = off).")
 flags.DEFINE_boolean("hip_graph", True, "replay the training step from a HIP graph (GPU only; steps of a different batch size run eagerly)")
@@ -118,9 +121,16 @@ def main(argv):
     sess = TrainingSession(model, engine, num_classes=len(flower_classes), hooks=hooks, global_step=global_step,
                            logits_act_l2=head_l2, hip_graph=FLAGS.hip_graph and device.type == "cuda")
 
+    image_cache = None
+    if device.type == "cuda":
+        from distributed_tensorflow_amd.data.jpeg import default_cache
+
+        image_cache = default_cache(device, FLAGS.image_cache_gb)
+
     def next_batch(pool, bs):
         if device.type == "cuda":
-            return flower_input_data.prepare_batch_on_device(pool, bs, device, FLAGS.image_size, np_rng=np_rng)
+            return flower_input_data.prepare_batch_on_device(pool, bs, device, FLAGS.image_size, np_rng=np_rng,
+                                                             cache=image_cache)
         X, y = flowers.prepare_batch(pool, bs, FLAGS.image_size, np_rng)
         Xp = np.zeros(X.shape[:3] + (8,), dtype=np.float32)
         Xp[..., :3] = X
@@ -132,7 +142,7 @@ def main(argv):
     if device.type == "cuda" and FLAGS.prefetch:
         from distributed_tensorflow_amd.data.prefetch import DevicePrefetcher
 
-        prefetcher = DevicePrefetcher(lambda: next_batch(train, batch_size), device)
+        prefetcher = DevicePrefetcher(lambda: next_batch(train, batch_size), device, depth=FLAGS.prefetch_depth)
     t0 = time.time()
     done = False
     with sess:
@@ -152,7 +162,7 @@ def main(argv):
             # the whole held-out split, each image once, no augmentation; example-weighted means
             n = 0
             acc_sum = loss_sum = 0.0
-            for X, y in flower_input_data.evaluation_batches(test, batch_size, device, FLAGS.image_size):
+            for X, y in flower_input_data.evaluation_batches(test, batch_size, device, FLAGS.image_size, cache=image_cache):
                 ev = sess.evaluate(X, y)
                 k = int(y.shape[0])
                 acc_sum, loss_sum, n = acc_sum + ev["accuracy"] * k, loss_sum + ev["loss"] * k, n + k

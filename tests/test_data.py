@@ -134,6 +134,7 @@ def _jpeg_bytes(img, **kw):
 
 @pytest.mark.parametrize("kw", [dict(quality=90, subsampling=0), dict(quality=75, subsampling=0),
                                 dict(quality=95, subsampling=2), dict(quality=85, subsampling=1),
+                                dict(quality=60, subsampling=2),
                                 dict(quality=90, subsampling=0, restart_marker_blocks=3)])
 def test_entropy_decoder_reproduces_libjpeg(kw):
     rng = np.random.default_rng(0)
@@ -147,12 +148,9 @@ def test_entropy_decoder_reproduces_libjpeg(kw):
     assert (info.width, info.height, info.ncomp) == (93, 67, 3)
     got = jpeg.reconstruct_reference(info, coefs).astype(np.int32)
     want = jpeg.decode_pil(data).astype(np.int32)
-    if kw["subsampling"] == 0:
-        # float IDCT + float colour conversion vs libjpeg's integer IDCT and fixed-point tables
-        assert np.abs(got - want).max() <= 3 and np.abs(got - want).mean() < 0.5
-    else:
-        # chroma replication vs libjpeg's triangle upsampling: small average difference only
-        assert np.abs(got - want).mean() < 3.0
+    # float IDCT + float colour conversion vs libjpeg's integer IDCT and fixed-point tables; subsampled chroma
+    # (4:2:2, 4:2:0) goes through the same triangle filters as libjpeg's "fancy" upsampling
+    assert np.abs(got - want).max() <= 3 and np.abs(got - want).mean() < 0.6
 
 
 def test_grayscale_and_unsupported_jpegs():

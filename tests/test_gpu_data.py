@@ -66,9 +66,10 @@ def test_jpeg_device_decode_matches_numpy_and_libjpeg():
         else:
             want = jpeg.decode_pil(data).astype(np.int32)  # progressive file: PIL fallback uploaded as pixels
             assert np.array_equal(got, want)
-    pil = jpeg.decode_pil(jpegs[0]).astype(np.int32)
-    got0 = host[offs[0]: offs[0] + pil.size].reshape(pil.shape).astype(np.int32)
-    assert np.abs(got0 - pil).max() <= 3
+    for k in (0, 1):   # 4:4:4 and 4:2:0 (triangle-filtered chroma) against libjpeg itself
+        pil = jpeg.decode_pil(jpegs[k]).astype(np.int32)
+        got_k = host[offs[k]: offs[k] + pil.size].reshape(pil.shape).astype(np.int32)
+        assert np.abs(got_k - pil).max() <= 3, k
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="bundled sample dataset missing (run tools/make_flower_fixture.py)")
@@ -158,3 +159,41 @@ def test_device_prefetcher_hands_over_batches_in_order():
     assert state["k"] >= 12
     with pytest.raises(ValueError):
         DevicePrefetcher(produce, "cpu")
+
+
+def test_decoded_image_cache_serves_pixels_from_the_device(tmp_path):
+    """Files are read and entropy-decoded once; later batches point the resize kernel at the cached pixels
+    (offsets relative to another buffer, modulo 2^64) and produce identical network inputs."""
+    import torch
+
+    from distributed_tensorflow_amd.data.preprocess import NORM_INCEPTION, full_crop, make_descs, resize_on_device
+
+    rng = np.random.default_rng(3)
+    paths = []
+    for i in range(6):
+        h, w = int(rng.integers(40, 90)), int(rng.integers(40, 90))
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        p = tmp_path / ("im%d.jpg" % i)
+        p.write_bytes(_jpeg_bytes(img, quality=90, subsampling=2 if i % 2 else 0))
+        paths.append(str(p))
+    cache = jpeg.DecodedImageCache("cuda", budget_bytes=1 << 20, arena_bytes=1 << 16)
+
+    def batch(sel):
+        base, shapes, offs = jpeg.decode_files_to_device([paths[i] for i in sel], "cuda", cache)
+        descs = torch.from_numpy(make_descs(shapes, offs, [full_crop(h, w) for h, w, _ in shapes])).cuda()
+        return resize_on_device(base, descs, len(sel), (32, 32), "bilinear", False, NORM_INCEPTION), base
+
+    x1, _ = batch([0, 1, 2, 3])
+    assert (cache.hits, cache.misses, len(cache)) == (0, 4, 4)
+    x2, base2 = batch([3, 2, 4, 0])       # three hits in two arenas and one miss in the same batch
+    assert (cache.hits, cache.misses, len(cache)) == (3, 5, 5)
+    assert torch.equal(x2[0], x1[3]) and torch.equal(x2[1], x1[2]) and torch.equal(x2[3], x1[0])
+    x3, base3 = batch([4, 0])             # all hits: nothing decoded, the base buffer is a dummy
+    assert base3.numel() == 16 and torch.equal(x3[0], x2[2]) and torch.equal(x3[1], x1[0])
+    # without a cache the same call decodes every time
+    base, shapes, offs = jpeg.decode_files_to_device(paths[:2], "cuda", None)
+    assert all(0 <= o < base.numel() for o in offs)
+    # a full cache stops storing but keeps serving
+    small = jpeg.DecodedImageCache("cuda", budget_bytes=20000, arena_bytes=1 << 16)
+    jpeg.decode_files_to_device(paths, "cuda", small)
+    assert 0 < len(small) < len(paths) and small.bytes_used <= 20000
