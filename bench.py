@@ -63,7 +63,10 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
 
     # synthetic batch generated on the device (a 2048 x 224 x 224 host tensor per rank would cost seconds and GBs)
     g = torch.Generator(device=device).manual_seed(1000 + rank)
-    images = torch.zeros(batch, size, size, 8, device=device, dtype=torch.bfloat16)
+    # image layout as the input pipeline delivers it: NHWC, 3 real channels padded to 8, or to 4 for models with the
+    # pixel-pair stem (ResNet-50 on the device, data.preprocess.resize_on_device(channels=4))
+    cpad = getattr(model, "input_channels", 8)
+    images = torch.zeros(batch, size, size, cpad, device=device, dtype=torch.bfloat16)
     images[..., :3] = (torch.rand(batch, size, size, 3, device=device, generator=g) * 2 - 1).to(torch.bfloat16)
     labels = torch.randint(0, 5, (batch,), device=device, generator=g).to(torch.int32)
 

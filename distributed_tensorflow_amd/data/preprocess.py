@@ -160,9 +160,11 @@ def make_descs(shapes: Sequence[Tuple[int, int, int]], offsets: Sequence[int],
 
 
 def resize_on_device(packed: torch.Tensor, descs: torch.Tensor, batch: int, out_hw: Tuple[int, int],
-                     method: str = "bilinear_legacy", bgr: bool = False, norm=NORM_INCEPTION) -> torch.Tensor:
+                     method: str = "bilinear_legacy", bgr: bool = False, norm=NORM_INCEPTION,
+                     channels: int = CHANNELS_PADDED) -> torch.Tensor:
     """packed: uint8 device buffer, descs: uint8 device buffer of ``_ImageDesc`` records.
-    Returns bf16 [B, OH, OW, 8]."""
+    Returns bf16 [B, OH, OW, channels] (3 real channels, the rest zero; 8 by default, 4 for models whose stem reads
+    pixel pairs, ``model.input_channels``)."""
     from ..ops import hipk
 
     if not packed.is_cuda or packed.dtype != torch.uint8 or not descs.is_cuda:
@@ -170,10 +172,12 @@ def resize_on_device(packed: torch.Tensor, descs: torch.Tensor, batch: int, out_
     if descs.numel() != batch * C.sizeof(_ImageDesc):
         raise ValueError("descriptor table size mismatch")
     OH, OW = out_hw
-    out = torch.empty((batch, OH, OW, CHANNELS_PADDED), dtype=torch.bfloat16, device=packed.device)
+    if channels < 3:
+        raise ValueError("at least the three colour channels")
+    out = torch.empty((batch, OH, OW, channels), dtype=torch.bfloat16, device=packed.device)
     a = _ResizeArgs()
     a.src, a.desc, a.dst = packed.data_ptr(), descs.data_ptr(), out.data_ptr()
-    a.B, a.OH, a.OW, a.CP = batch, OH, OW, CHANNELS_PADDED
+    a.B, a.OH, a.OW, a.CP = batch, OH, OW, channels
     a.method, a.bgr = METHODS[method], 1 if bgr else 0
     for k in range(3):
         a.scale[k] = norm[0][k]

@@ -44,8 +44,9 @@ class RecordInput:
     def __init__(self, path: str, batch_size: int, device, *, image_size: int = 299, num_epochs: int = 1,
                  rank: int = 0, world: int = 1, threads: int = 4, prefetch: int = 4, shuffle: bool = True,
                  seed: int = 0, drop_remainder: bool = False, legacy_bgr_unnormalised: bool = False,
-                 max_image_bytes: int = 1 << 20):
+                 max_image_bytes: int = 1 << 20, channels: int = 8):
         self.device = torch.device(device)
+        self.channels = channels   # channel count of the produced images (3 real + zero padding; device path)
         if self.device.type == "cuda" and self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.batch_size, self.image_size = batch_size, image_size
@@ -132,7 +133,7 @@ class RecordInput:
                 nb = n * C.sizeof(_ImageDesc)
                 self._desc_pin[b.slot][:nb].copy_(torch.from_numpy(descs.view(np.uint8)))
                 dd = self._desc_pin[b.slot][:nb].to(self.device, non_blocking=True)
-                x = resize_on_device(dev, dd, n, size, "bilinear_legacy", bgr_to_rgb, norm)
+                x = resize_on_device(dev, dd, n, size, "bilinear_legacy", bgr_to_rgb, norm, channels=self.channels)
                 self._lab_pin[b.slot][:n].copy_(labels)
                 lab = self._lab_pin[b.slot][:n].to(self.device, non_blocking=True)
                 if not release:
@@ -173,11 +174,11 @@ class SyntheticInput:
     """Endless random batches with flower_photos-like shape (for throughput measurement)."""
 
     def __init__(self, batch_size: int, image_size: int, device, num_classes: int = 5, seed: int = 0,
-                 dtype: Optional[torch.dtype] = None):
+                 dtype: Optional[torch.dtype] = None, channels: int = 8):
         device = torch.device(device)
         g = torch.Generator().manual_seed(seed)
         dtype = dtype or (torch.bfloat16 if device.type == "cuda" else torch.float32)
-        x = torch.zeros(batch_size, image_size, image_size, 8)
+        x = torch.zeros(batch_size, image_size, image_size, channels)
         x[..., :3] = torch.rand(batch_size, image_size, image_size, 3, generator=g) * 2 - 1
         self.x = x.to(device=device, dtype=dtype)
         self.y = torch.randint(0, num_classes, (batch_size,), generator=g).to(device=device, dtype=torch.int32)

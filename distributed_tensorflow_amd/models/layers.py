@@ -61,12 +61,18 @@ class ConvBnAct(nn.Module):
             if t is not None:
                 t._keep_fp32 = True
 
-    def forward_pool(self, x, kernel=(3, 3), stride=(2, 2), padding="VALID"):
-        """This layer followed by a max-pool, fused on the device (the un-pooled activation is not stored)."""
+    def forward_pool(self, x, kernel=(3, 3), stride=(2, 2), padding="VALID", weight=None, conv_stride=None,
+                     conv_padding=None):
+        """This layer followed by a max-pool, fused on the device (the un-pooled activation is not stored).
+        ``weight`` / ``conv_stride`` / ``conv_padding`` run the layer as an equivalent convolution over a
+        re-interpreted input (a differentiable function of ``self.weight``, see ``models.resnet``)."""
         if self.training:
             self._coeff_cache = None  # the kernels update the running statistics in place, behind torch's versions
-        return F.conv_bn_act_pool(x, self.weight, self.gamma, self.beta, self.running_mean, self.running_var,
-                                  stride=self.stride, padding=self.padding, eps=self.eps, momentum=self.momentum,
+        return F.conv_bn_act_pool(x, self.weight if weight is None else weight, self.gamma, self.beta,
+                                  self.running_mean, self.running_var,
+                                  stride=self.stride if conv_stride is None else conv_stride,
+                                  padding=self.padding if conv_padding is None else conv_padding,
+                                  eps=self.eps, momentum=self.momentum,
                                   relu=self.relu, training=self.training, pool_kernel=_pair(kernel),
                                   pool_stride=_pair(stride), pool_padding=padding)
 
@@ -152,4 +158,7 @@ def cast_for_device(module: nn.Module, device, compute_dtype=None) -> nn.Module:
     for name, b in list(module.named_buffers()):
         b.data = b.data.to(device=device)
     module.compute_dtype = compute_dtype
+    if hasattr(module, "input_channels") and hasattr(module, "_pair_idx"):
+        # preferred image layout of this replica (both layouts are accepted wherever they are valid)
+        module.input_channels = 4 if device.type == "cuda" else 8
     return module

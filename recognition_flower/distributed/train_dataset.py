@@ -119,14 +119,15 @@ def _num_classes():
     return 5  # the reference hard-codes n_outputs=5
 
 
-def train_input_fn(tfrecords_path, params, device, rank, world):
+def train_input_fn(tfrecords_path, params, device, rank, world, channels=8):
     from distributed_tensorflow_amd.data.records import RecordInput, SyntheticInput
 
     if FLAGS.synthetic:
-        return SyntheticInput(params["batch_size"], FLAGS.image_size, device, seed=rank)
+        return SyntheticInput(params["batch_size"], FLAGS.image_size, device, seed=rank, channels=channels)
     return RecordInput(tfrecords_path, params["batch_size"], device, image_size=FLAGS.image_size,
                        num_epochs=params["num_epochs"], rank=rank, world=world, threads=params["threads"],
-                       prefetch=4, shuffle=True, seed=1234, legacy_bgr_unnormalised=FLAGS.legacy_bgr_input)
+                       prefetch=4, shuffle=True, seed=1234, legacy_bgr_unnormalised=FLAGS.legacy_bgr_input,
+                       channels=channels)
 
 
 def run_ps(spec):
@@ -252,7 +253,9 @@ def run_worker(spec):
     sess = TrainingSession(model, engine, num_classes=n_classes, hooks=hooks, is_chief=is_chief, reg_weight=0.01,
                            logits_act_l2=0.01 * head_l2, global_step=start_step,
                            hip_graph=_want_hip_graph() and device.type == "cuda")
-    data = train_input_fn(FLAGS.tfrecords_path, params, device, task_index, world)
+    # (image layout the model's stem prefers on this device: 8 channels, or 4 for the pixel-pair stem)
+    data = train_input_fn(FLAGS.tfrecords_path, params, device, task_index, world,
+                          channels=getattr(model, "input_channels", 8) if FLAGS.image_size % 2 == 0 else 8)
     fault_step = int(FLAGS.fault_inject.split(":")[1]) if FLAGS.fault_inject.startswith("exit_at_step:") else None
     t0 = time.time()
     with sess:
@@ -330,7 +333,8 @@ def run_evaluator(spec):
             seen, last_new = prefix, time.time()
             continue
         seen, last_new = prefix, time.time()
-        data = train_input_fn(FLAGS.tfrecords_path, eval_params, device, 0, 1)
+        data = train_input_fn(FLAGS.tfrecords_path, eval_params, device, 0, 1,
+                              channels=getattr(model, "input_channels", 8) if FLAGS.image_size % 2 == 0 else 8)
         n = correct = 0
         loss_sum = 0.0
         with torch.no_grad():

@@ -242,3 +242,36 @@ def test_inception_branches_on_streams_equal_sequential(monkeypatch):
                 graph.replay()
             torch.cuda.synchronize()
             assert torch.equal(seq, out)
+
+
+def test_resnet_pixel_pair_stem_equals_the_8_channel_stem():
+    """[B, H, W, 4] images (pixel-pair stem: a 7x4 / stride-(2,1) convolution over [B, H, W/2, 8], K = 224) give the
+    logits and the parameter gradients of the same images stored with 8 channels (7x7 / stride 2, K = 392)."""
+    torch.manual_seed(0)
+    model = build_model("resnet50", device="cuda", zero_init_residual=False).train()
+    assert model.input_channels == 4
+    x8, y = _images(8, 64, seed=5)
+    x8 = x8.cuda().bfloat16()
+    x4 = x8[..., :4].contiguous()
+    y = y.cuda().to(torch.int32)
+
+    def run(x):
+        model.zero_grad(set_to_none=True)
+        for m in model.modules():
+            if hasattr(m, "running_mean"):
+                m.running_mean.zero_()
+                m.running_var.fill_(1.0)
+        logits = model(x)
+        loss, _, _, _ = F.softmax_xent(logits, y, 5)
+        loss.backward()
+        return logits.detach().float().cpu(), {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}
+
+    l8, g8 = run(x8)
+    l4, g4 = run(x4)
+    # same products in a different summation order (k-tiles of the stem differ): bf16-level agreement
+    assert (l8 - l4).abs().max().item() <= 3e-2 * l8.abs().max().item() + 1e-3
+    gs8, gs4 = g8["stem.weight"], g4["stem.weight"]
+    assert gs4[..., 3:].abs().max().item() == 0.0           # pad channels receive no gradient
+    assert (gs8[..., :3] - gs4[..., :3]).norm().item() <= 5e-2 * gs8[..., :3].norm().item()
+    for n in ("blocks.0.conv1.weight", "blocks.15.conv3.weight", "fc.weight"):
+        assert (g8[n] - g4[n]).norm().item() <= 8e-2 * g8[n].norm().item() + 1e-6, n
