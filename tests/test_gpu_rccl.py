@@ -53,3 +53,18 @@ def test_bench_under_torchrun_one_rank(extra):
         assert comm["buckets"] > 1  # (a bucket holds whole tensors, so one may exceed the nominal size)
     if "--hip_graph" not in extra and "--p2p_kb" not in extra:
         assert comm["collectives_waited"] >= 4 and comm["exposed_wait_ms_per_step"] >= 0.0
+
+
+@pytest.mark.parametrize("extra", [["--mode", "sync_dp"], ["--mode", "sharded_ps", "--hip_graph", "1"]])
+def test_resnet50_bench_under_torchrun_one_rank(extra):
+    """The headline model (folded bottleneck tails, pixel-pair stem, gated-gradient handoff between blocks) through
+    the same launcher and collectives as a multi-GPU job."""
+    env = dict(os.environ, DTFA_FORCE_COLLECTIVES="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", _port(), "bench.py", "--gpus", "1", "--model", "resnet50", "--batch", "16",
+           "--steps", "3", "--warmup", "2", "--also", "", "--also_modes", ""] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["model"] == "resnet50" and out["value"] > 0 and out["final_loss"] < 5.0
+    assert out["comm"]["collective"] is True and out["comm"]["buckets"] >= 1

@@ -63,7 +63,7 @@ def main():
     dev = torch.device("cuda", 0)
     model = build_model(args.model, num_classes=5, device=dev).train()
     eng = DataParallelEngine(model, mode="sync_dp", optimizer="momentum", lr=0.05, opt_kwargs={"momentum": 0.9, "weight_decay": 1e-4})
-    x = torch.zeros(args.batch, args.size, args.size, 8, device=dev, dtype=torch.bfloat16)
+    x = torch.zeros(args.batch, args.size, args.size, getattr(model, "input_channels", 8), device=dev, dtype=torch.bfloat16)
     x[..., :3] = torch.randn(args.batch, args.size, args.size, 3, device=dev).to(torch.bfloat16)
     y = torch.randint(0, 5, (args.batch,), dtype=torch.int32, device=dev)
 
