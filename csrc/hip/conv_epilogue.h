@@ -152,6 +152,12 @@ __device__ __forceinline__ void epi_prefetch(const ConvArgs& p, EpiPrefetch<BM, 
   }
 }
 
+// Timing-only builds for attributing epilogue time (results are wrong): -DEPI_DBG bit 0 drops the gate-bit loads of
+// a tap, bit 1 the final reduction and store of its sums, bit 2 the staging of the accumulators through LDS.
+#ifndef EPI_DBG
+#define EPI_DBG 0
+#endif
+
 template <int BM, int BN, int EPI, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[BM / 64][BN / 64], char* lds_tiles,
                                               int w4, int lane, int m0, int n0, unsigned tile_m, bool valid,
@@ -284,7 +290,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
         }
         if (EPI == 3) {
           if (has_bny) q.bnyv[i] = epi_load((const bf16x8*)(p.bn_y + off));
+#if (EPI_DBG & 1)
+          q.bnm[i] = 0xffu;
+#else
           q.bnm[i] = from_pre ? pre->bnm[i] : (p.bn_relu == 3 ? (unsigned)p.bn_mask[off >> 3] : 0xffu);
+#endif
         }
       }
     };
@@ -383,40 +393,46 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
       bs2p_out[j] = bs2p[j];
     }
   }
-  if (EPI == 3) {
+  if (EPI == 3 && !(EPI_DBG & 2)) {
+    // Per-column totals of the tile: every lane parks its eight sums in its wave's (now idle) row-tile area,
+    // lane-linear; after the barrier thread c of the group adds the 2 wave rows x (64 / CPR) row groups of
+    // column c in a fixed order and stores one float -- a coalesced row of BN values per plane.
+    const bool has_bny2 = p.bn_y != nullptr;
+    float* red = (float*)ep;   // this wave's region: [lane][8] per plane
+    // both planes side by side where a wave's region holds them (2 x 2 KB), else one after the other
+    constexpr bool ONE_ROUND = WM * EP_PITCH >= 4096;
+    const int t = w4 * 64 + lane;   // thread index inside the 2 x 2 wave group
+    const bool reader = t < BN && n0 + t < p.Cout && valid;
+    const int cwc = t / WN, cc = t % WN;
+    const int at = (cc >> 3) * 8 + (cc & 7);
+    const size_t prow = (size_t)tile_m * 2;
+    auto park = [&](const f32x2 (&v)[4], int plane_off) {
+      *(f32x4*)(red + plane_off + lane * 8) = f32x4{v[0].x, v[0].y, v[1].x, v[1].y};
+      *(f32x4*)(red + plane_off + lane * 8 + 4) = f32x4{v[2].x, v[2].y, v[3].x, v[3].y};
+    };
+    auto column_total = [&](int plane_off) {
+      float a = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bs1[2 * j] = bs1p_out[j].x;
-      bs1[2 * j + 1] = bs1p_out[j].y;
-      bs2[2 * j] = bs2p_out[j].x;
-      bs2[2 * j + 1] = bs2p_out[j].y;
-    }
-    // lanes that share a chunk column differ in the lane bits above log2(CPR): fold those
+      for (int wrow = 0; wrow < 2; ++wrow) {
+        const float* rw = (const float*)(lds_tiles + (wrow * 2 + cwc) * (WM * EP_PITCH));
 #pragma unroll
-    for (int sh = CPR; sh < 64; sh <<= 1) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        bs1[j] += __shfl_xor(bs1[j], sh, 64);
-        bs2[j] += __shfl_xor(bs2[j], sh, 64);
+        for (int rg = 0; rg < 64 / CPR; ++rg) a += rw[plane_off + rg * CPR * 8 + at];
       }
-    }
-    const int co = chunk_co;
-    float* mine = xch + (wc * WN + (lane % CPR) * 8) * 2;
-    if (wr == 1 && lane < CHUNKS) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        mine[j * 2] = bs1[j];
-        mine[j * 2 + 1] = bs2[j];
-      }
-    }
+      return a;
+    };
+    park(bs1p_out, 0);
+    if (ONE_ROUND && has_bny2) park(bs2p_out, 512);
     __syncthreads();
-    if (wr == 0 && lane < CHUNKS && co < p.Cout && valid) {
-      const size_t prow = (size_t)tile_m * 2;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        p.stats[prow * p.Cout + co + j] = bs1[j] + mine[j * 2];
-        p.stats[(prow + 1) * p.Cout + co + j] = bs2[j] + mine[j * 2 + 1];
-      }
+    if (reader) {
+      p.stats[prow * p.Cout + n0 + t] = column_total(0);
+      if (!has_bny2) p.stats[(prow + 1) * p.Cout + n0 + t] = 0.f;
+      else if (ONE_ROUND) p.stats[(prow + 1) * p.Cout + n0 + t] = column_total(512);
+    }
+    if (!ONE_ROUND && has_bny2) {
+      __syncthreads();
+      park(bs2p_out, 0);
+      __syncthreads();
+      if (reader) p.stats[(prow + 1) * p.Cout + n0 + t] = column_total(0);
     }
   }
 }
