@@ -34,8 +34,12 @@ struct WgradArgs {
 
 #define MAX_TAPS 64
 
+// XOR applied to the 16-byte chunk index of tile row ``row`` (RB bytes per row).  A transposed fragment read
+// touches 64 bytes in each of four consecutive rows: rows of 256 bytes or more all start at bank 0, so the
+// swizzle moves row r by (r & 3) * 64 bytes; with 128-byte rows two rows share a bank row and pairs are moved.
 template <int RB>
 __device__ __forceinline__ int wswz(int row) {
+  if (RB >= 256) return (row & 3) << 2;
   constexpr int RBR = 256 / RB;  // rows per 256-byte bank row
   return ((row / RBR) & (4 / RBR - 1)) << 2;
 }
@@ -93,13 +97,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 
   // ---- A' (dY) staging rows ----
   const int a_row = lane / CPRA;                                 // row within instruction
-  const int a_chunk = (lane % CPRA) ^ wswz<RBA>(a_row);          // logical chunk (RPIA % 4 == 0)
+  // logical chunk: tile row of instruction i is (i * 4 + wid) * RPIA + a_row, and 4 * RPIA rows repeat the swizzle
+  const int a_chunk = (lane % CPRA) ^ wswz<RBA>(wid * RPIA + a_row);
   const int a_co = co0 + a_chunk * 8;
   const bool a_ok = a_co < p.Cout;
 
   // ---- B' (X gather) staging rows ----
   const int b_row = lane / CPRB;
-  const int b_chunk = (lane % CPRB) ^ wswz<RBB>(b_row);
+  const int b_chunk = (lane % CPRB) ^ wswz<RBB>(wid * RPIB + b_row);
   const int b_n = n0 + b_chunk * 8;
   const bool b_kok = b_n < p.K;
   int b_tap = (int)__umulhi((unsigned)b_n, p.cin_magic);
@@ -342,6 +347,9 @@ extern "C" int dtfa_conv_wgrad(WgradArgs* a, int bmw, int bnw, int bkp, int spli
   a->step_x = rem % a->OW;
 #define CASE(A_, B_, C_) \
   if (bmw == A_ && bnw == B_ && bkp == C_) return launch_wgrad<A_, B_, C_>(*a, splits, stream);
+  CASE(256, 128, 32)
+  CASE(128, 256, 32)
+  CASE(64, 256, 32)
   CASE(128, 128, 32)
   CASE(64, 128, 32)
   CASE(128, 64, 32)

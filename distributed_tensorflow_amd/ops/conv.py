@@ -200,6 +200,9 @@ def pick_fwd_tile(M: int, cout: int, K: int, dense: bool = True) -> Tuple[int, i
     return bm, bn, bk, (2 if bk == 64 else 3)
 
 
+_WGRAD_WIDE = os.environ.get("DTFA_WGRAD_WIDE", "1") == "1"
+
+
 def pick_wgrad_tile(M: int, cout: int, K: int, cin: int = 0) -> Tuple[int, int, int, int]:
     forced = _env_tile("DTFA_WGRAD_TILE")
     bmw = 128 if cout > 64 else 64
@@ -210,6 +213,14 @@ def pick_wgrad_tile(M: int, cout: int, K: int, cin: int = 0) -> Tuple[int, int, 
     # large batch) is bound by streaming dY and X: a 64-pixel k-step halves the barriers per byte moved
     # (+4 .. 10 % there); everywhere else 32 pixels with three stages measured faster
     bkp = 64 if (128 <= K <= 256 and cout <= 128 and M >= 1 << 20) else 32
+    # 256-wide tiles (each wave 128 x 64 or 64 x 128 / 32 x 128: more MFMAs per fragment read) where they waste no
+    # columns: measured at batch 2048, -10 % on the 14x14 3x3 layers, -4 .. 8 % on the 1x1 layers with 256 or 1024
+    # output channels, -8 % on 56x56 256 -> 64; slower wherever K or Cout does not fill them (3x3 with 64 / 128
+    # channels: K = 576 / 1152 is 2.25 / 4.5 tiles)
+    if _WGRAD_WIDE and cout % 256 == 0:
+        bmw, bnw, bkp = 256, 128, 32
+    elif _WGRAD_WIDE and cout <= 64 and cin > 0 and K == cin and K % 256 == 0:
+        bmw, bnw, bkp = 64, 256, 32
     if forced:
         bmw, bnw, bkp = forced[:3]
     tiles = -(-cout // bmw) * -(-K // bnw)

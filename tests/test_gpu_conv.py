@@ -25,6 +25,9 @@ CASES = [
     (2, 28, 28, 128, 128, 3, 3, 1, 1, "SAME"),      # resnet 3x3, four chunks per tap
     (1, 57, 57, 64, 72, 3, 3, 1, 1, "SAME"),        # wide rows, Cout tail
     (2, 20, 20, 96, 64, 3, 1, 1, 1, "SAME"),        # 3 taps, narrow output tile
+    (2, 14, 14, 256, 256, 3, 3, 1, 1, "SAME"),      # weight gradient on the 256 x 128 tile
+    (3, 9, 9, 64, 512, 1, 1, 1, 1, "VALID"),        # 256 x 128 tile with a half-filled K tile
+    (2, 12, 12, 256, 64, 1, 1, 1, 1, "VALID"),      # weight gradient on the 64 x 256 tile
 ]
 
 
