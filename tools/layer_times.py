@@ -69,8 +69,10 @@ def main():
 
     def step():
         eng.begin_step()
-        loss, _, _, _ = F.softmax_xent(model(x), y, 5)
-        loss.backward()
+        out = model(x)
+        logits, reg = out if isinstance(out, tuple) else (out, None)
+        loss, _, _, _ = F.softmax_xent(logits, y, 5)
+        (loss if reg is None else loss + reg).backward()
         eng.finish_step()
 
     for _ in range(2):
