@@ -39,6 +39,7 @@ struct ConvArgs {
   // bias / ReLU epilogue only (inference with folded batch-norm, dense layers):
   int ldo;                       // channel pitch of the output rows (> Cout: y is a channel slice of a wider tensor)
   const float* oscale;           // [Cout] multiplier applied to the accumulator before the bias, or null
+  int stream_out;                // the output is far larger than the caches: store it non-temporally
   unsigned char* omask;          // bias / ReLU epilogue with ReLU: one bit per output element, (out > 0), or null
   // data-gradient epilogues (EPI 0 / 3):
   const float* dbias;            // [Cout] added to the accumulator before rounding, or null
@@ -324,7 +325,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
               v[j] = w;
             }
           }
-          out_store((bf16x8*)(p.y + q.ooff[i]), __builtin_bit_cast(bf16x8, v));
+          if (p.stream_out) __builtin_nontemporal_store(__builtin_bit_cast(bf16x8, v), (bf16x8*)(p.y + q.ooff[i]));
+          else out_store((bf16x8*)(p.y + q.ooff[i]), __builtin_bit_cast(bf16x8, v));
           if (EPI == 2 && p.omask != nullptr) {
             // sign bits of the activation (training: all the backward pass needs of it); dense outputs only.
             // After a ReLU a value is positive exactly when its bf16 word is non-zero.
@@ -365,7 +367,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
               gv[j] = gw;
             }
           }
-          out_store((bf16x8*)(p.y + q.ooff[i]), __builtin_bit_cast(bf16x8, gate_store ? gv : v));
+          if (p.stream_out) __builtin_nontemporal_store(__builtin_bit_cast(bf16x8, gate_store ? gv : v), (bf16x8*)(p.y + q.ooff[i]));
+          else out_store((bf16x8*)(p.y + q.ooff[i]), __builtin_bit_cast(bf16x8, gate_store ? gv : v));
         }
       }
     };
