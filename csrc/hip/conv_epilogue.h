@@ -47,6 +47,10 @@ struct ConvArgs {
   // pointwise launches: reduction indices >= K1 read a second operand x2 ([M][K - K1]); K1 == K: single operand
   const bf16* x2;
   int K1;
+  // data-gradient epilogues with a dense output: the addend lives on a coarser pixel grid (the gradient of a strided
+  // shortcut): output pixel (b, oy, ox) receives addend pixel (b, oy >> shy, ox >> shx) when oy and ox are
+  // multiples of the stride (1 << shy, 1 << shx) and nothing otherwise.  0 / 0: the addend has the output's shape.
+  int addend_shy, addend_shx;
 };
 
 #define MAX_TAPS 64
@@ -123,6 +127,19 @@ __device__ __forceinline__ size_t epi_out_offset(const ConvArgs& p, int ldo, int
   return opixel * ldo + chunk_co;
 }
 
+// Element offset of the addend chunk for output pixel ``pixel`` when the addend is on a coarser grid (see
+// ConvArgs::addend_shy); ``live`` is false for pixels between the grid points.
+__device__ __forceinline__ size_t epi_coarse_addend_offset(const ConvArgs& p, size_t pixel, int chunk_co, bool& live) {
+  const unsigned m = (unsigned)pixel;
+  const unsigned opix = (unsigned)(p.OH * p.OW);
+  const unsigned b = m / opix, rem = m - b * opix;
+  const unsigned oy = rem / (unsigned)p.OW, ox = rem - oy * (unsigned)p.OW;
+  const unsigned my = (1u << p.addend_shy) - 1u, mx = (1u << p.addend_shx) - 1u;
+  live = ((oy & my) | (ox & mx)) == 0u;
+  const unsigned ah = ((unsigned)p.OH + my) >> p.addend_shy, aw = ((unsigned)p.OW + mx) >> p.addend_shx;
+  return (((size_t)b * ah + (oy >> p.addend_shy)) * aw + (ox >> p.addend_shx)) * p.Cout + chunk_co;
+}
+
 // The epilogue's operand loads of the first G readback passes (residual / residual gradient and the gate bits).  They do not depend on the GEMM, so a kernel whose reduction is short (a 1x1
 // layer with few input channels is two k-tiles) issues them before its main loop: the tile then pays the
 // memory latency once, not once for the operand tiles and again for the epilogue.
@@ -146,8 +163,15 @@ __device__ __forceinline__ void epi_prefetch(const ConvArgs& p, EpiPrefetch<BM, 
     const size_t o = epi_out_offset<BM, BN>(p, ldo, w4, lane, m0, n0, i, ok, pixel);
     const size_t off = ok ? (EPI == 2 ? pixel * p.Cout + chunk_co : o) : 0;  // idle lanes read an in-range dummy
     if (p.addend != nullptr) {
-      r.addv[i] = epi_load((const bf16x8*)(p.addend + off));
-      r.addm[i] = (EPI != 2 && p.addend_mask != nullptr) ? (unsigned)p.addend_mask[off >> 3] : 0xffu;
+      if (EPI != 2 && (p.addend_shy | p.addend_shx) != 0) {
+        bool live;
+        const size_t aoff = epi_coarse_addend_offset(p, pixel, chunk_co, live);
+        r.addv[i] = (ok && live) ? epi_load((const bf16x8*)(p.addend + aoff)) : bf16x8{};
+        r.addm[i] = 0xffu;
+      } else {
+        r.addv[i] = epi_load((const bf16x8*)(p.addend + off));
+        r.addm[i] = (EPI != 2 && p.addend_mask != nullptr) ? (unsigned)p.addend_mask[off >> 3] : 0xffu;
+      }
     }
     if (EPI == 3) r.bnm[i] = p.bn_relu == 3 ? (unsigned)p.bn_mask[off >> 3] : 0xffu;
   }
@@ -266,6 +290,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
     const bool has_add = EPI != 1 && p.addend != nullptr;
     const bool has_addm = (EPI == 0 || EPI == 3) && p.addend_mask != nullptr;
     const bool has_bny = EPI == 3 && p.bn_y != nullptr;
+    const bool coarse_add = (EPI == 0 || EPI == 3) && (p.addend_shy | p.addend_shx) != 0;
     const bool gate_store = EPI == 3 && p.bn_gate_store != 0;
     struct Group {
       size_t ooff[G];
@@ -284,6 +309,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
           if (from_pre) {
             q.addv[i] = pre->addv[i];
             q.addm[i] = pre->addm[i];
+          } else if (coarse_add) {
+            bool live;
+            const size_t aoff = epi_coarse_addend_offset(p, last_pixel, chunk_co, live);
+            q.addv[i] = (q.ook[i] && live) ? epi_load((const bf16x8*)(p.addend + aoff)) : bf16x8{};
+            q.addm[i] = 0xffu;
           } else {
             q.addv[i] = epi_load((const bf16x8*)(p.addend + off));
             q.addm[i] = has_addm ? (unsigned)p.addend_mask[off >> 3] : 0xffu;

@@ -419,6 +419,10 @@ extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int ns
   if (a->dbias != nullptr && (a->bias != nullptr || a->relu || a->oscale != nullptr)) return -4;
   if (a->x2 != nullptr && (!a->pointwise || a->K1 <= 0 || a->K1 >= a->K || a->K1 % 8 != 0)) return -7;
   if (a->x2 == nullptr && a->K1 != a->K) return -7;
+  if ((a->addend_shy | a->addend_shx) != 0 &&
+      (a->addend == nullptr || fwd_residual || !a->dense_out || a->addend_mask != nullptr || a->addend_shy < 0 ||
+       a->addend_shy > 4 || a->addend_shx < 0 || a->addend_shx > 4 || a->M != (long long)(a->M / (a->OH * a->OW)) * a->OH * a->OW))
+    return -8;
   if (a->bn_y != nullptr) {
     if (a->stats == nullptr || a->bn_mean == nullptr || a->bn_invstd == nullptr || a->bias != nullptr || a->relu) return -5;
     if (a->bn_relu == 2 && (a->bn_scale == nullptr || a->bn_shift == nullptr)) return -5;

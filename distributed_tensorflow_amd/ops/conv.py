@@ -225,7 +225,17 @@ def pick_wgrad_tile(M: int, cout: int, K: int, cin: int = 0) -> Tuple[int, int, 
         bmw, bnw, bkp = forced[:3]
     tiles = -(-cout // bmw) * -(-K // bnw)
     kt_total = -(-M // bkp)
-    splits = max(1, min(-(-1024 // tiles), max(1, kt_total // 8), 1024))
+    # Workgroups to aim for.  Every split writes its tile as fp32 partials that a second kernel sums, so splits cost
+    # traffic: a 1x1 layer is bound by streaming its two operands once and measured fastest with two workgroups per
+    # CU (one when a single large tile covers the whole gradient: -5 .. 12 % against four per CU); layers with taps
+    # re-read their operands from cache, run at a lower rate per workgroup, and want eight per CU.
+    if K != cin or cin <= 0:
+        want = 2048
+    elif tiles <= 2 and bmw * bnw >= 128 * 128:
+        want = 256
+    else:
+        want = 512
+    splits = max(1, min(-(-want // tiles), max(1, kt_total // 8), 1024))
     if forced and len(forced) > 3:
         splits = forced[3]
     return bmw, bnw, bkp, splits
@@ -240,7 +250,7 @@ STREAM_OUT_BYTES = int(os.environ.get("DTFA_CONV_STREAM_OUT_BYTES", str(256 << 2
 
 def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, osx, oy0, ox0, isy, isx, B,
                   cin_magic, bias=None, relu=False, stats=False, addend=None, zero_taps=False, addend_mask=None,
-                  bn_tap=None, oscale=None, ldo=0, omask=None, dbias=None, x2=None):
+                  bn_tap=None, oscale=None, ldo=0, omask=None, dbias=None, x2=None, addend_shift=(0, 0)):
     M = B * oyn * oxn
     K = T * cin + (x2.shape[-1] if x2 is not None else 0)
     dense_out = osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow
@@ -264,6 +274,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     a.omask, a.dbias, a.x2 = hipk.ptr(omask), hipk.ptr(dbias), hipk.ptr(x2)
     a.stream_out = 1 if M * cout * 2 >= STREAM_OUT_BYTES else 0
     a.K1 = T * cin
+    a.addend_shy, a.addend_shx = addend_shift
     a.zero = hipk.zero_page(x.device).data_ptr()
     a.taps = taps.data_ptr()
     a.IH, a.IW, a.Cin = ih, iw, cin
@@ -532,13 +543,25 @@ def dgrad_can_tap(plan: ConvPlan) -> bool:
     return len(plan.phases) == 1 and not plan.dgrad_needs_zero
 
 
+def dgrad_coarse_addend_ok(plan: ConvPlan, stride) -> bool:
+    """The data gradient of ``plan`` can add a gradient that lives on the grid ``[::sy, ::sx]`` of its output: one launch
+    over a dense output, strides powers of two up to 16."""
+    sy, sx = stride
+    return (dgrad_can_tap(plan) and plan.sy == 1 and plan.sx == 1 and 1 <= sy <= 16 and 1 <= sx <= 16
+            and sy & (sy - 1) == 0 and sx & (sx - 1) == 0)
+
+
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Optional[torch.Tensor] = None,
                addend_mask: Optional[torch.Tensor] = None, bn_tap: Optional[BnBackwardTap] = None,
                wd: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None,
-               dbias: Optional[torch.Tensor] = None) -> torch.Tensor:
+               dbias: Optional[torch.Tensor] = None, addend_stride: Tuple[int, int] = (1, 1)) -> torch.Tensor:
     """dy [B,OH,OW,Cout] -> dx [B,IH,IW,Cin] (+ ``addend``, e.g. the gradient arriving over a
     residual connection, fused into the epilogue instead of a separate add pass; ``addend_mask`` holds
     one bit per element of ``addend`` and only set elements are added).
+
+    ``addend_stride`` (sy, sx), powers of two: ``addend`` is [B, ceil(IH/sy), ceil(IW/sx), Cin] and lands on the pixels
+    ``dx[:, ::sy, ::sx]`` -- the gradient of a strided 1x1 shortcut reading the same input, added without ever being
+    scattered into a full-resolution tensor (see ``dgrad_coarse_addend_ok``).
 
     Pointwise layers only: ``wd`` ([Cin, K] bf16) replaces the permuted weight matrix; with ``x2`` ([B,OH,OW,C2]
     bf16) the reduction runs over ``[dy | x2]`` (K = Cout + C2), i.e. ``dx = dy @ wd[:, :Cout].T + x2 @
@@ -568,7 +591,10 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Option
     L = hipk.lib()
     if addend is not None:
         hipk.require(addend, torch.bfloat16, "addend")
-        if tuple(addend.shape) != (B, plan.ih, plan.iw, plan.cin):
+        asy, asx = addend_stride
+        if (asy, asx) != (1, 1) and (not dgrad_coarse_addend_ok(plan, addend_stride) or addend_mask is not None):
+            raise ValueError("a coarse-grid addend needs a single-launch unit-stride data gradient and power-of-two strides")
+        if tuple(addend.shape) != (B, -(-plan.ih // asy), -(-plan.iw // asx), plan.cin):
             raise ValueError("addend shape does not match dx")
         if plan.dgrad_needs_zero:
             raise ValueError("addend fusion needs every input pixel to be written by a dgrad phase")
@@ -594,7 +620,9 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Option
         part = _launch_igemm(dy, wp, dx, ph.taps, ph.T, plan.oh, plan.ow, plan.cout, plan.ih, plan.iw, plan.cin,
                              ph.OYn, ph.OXn, plan.sy, plan.sx, ph.oy0, ph.ox0, 1, 1, B, plan.cout_magic,
                              addend=addend, zero_taps=plan.is_pointwise, addend_mask=addend_mask, bn_tap=bn_tap,
-                             x2=x2, dbias=dbias)
+                             x2=x2, dbias=dbias,
+                             addend_shift=(addend_stride[0].bit_length() - 1, addend_stride[1].bit_length() - 1)
+                             if addend is not None else (0, 0))
         if bn_tap is not None:
             bn_tap.partials = part
             bn_tap.gated = bn_tap.gate_store

@@ -159,24 +159,39 @@ class GradSlot:
       data-gradient kernel; with ``mask`` (one bit per element) only the set elements are added, so
       ``g`` itself is never written -- the incoming ``dout`` and the stored sign bits are enough;
     * ``mask`` alone: the sign bits of the activation a layer's output was added into; that layer's
-      batch-norm backward gates its incoming gradient with them.
+      batch-norm backward gates its incoming gradient with them;
+    * ``stride`` (sy, sx) with ``grad``: the gradient lives on the pixels ``[::sy, ::sx]`` of the consumer's tensor
+      (a strided shortcut read the same input); the consumer adds it there, or scatters it if it cannot.
 
     Producers run before consumers by data dependency, except for ``input_grad_out_slot`` (a sibling
     branch): there ``consumed`` tells the producer that the consumer already ran, and it falls back to
     returning its gradient through autograd."""
 
-    __slots__ = ("grad", "mask", "consumed")
+    __slots__ = ("grad", "mask", "consumed", "stride")
 
     def __init__(self):
         self.grad = None
         self.mask = None
         self.consumed = False
+        self.stride = (1, 1)
 
     def take(self):
         g, m = self.grad, self.mask
         self.grad = self.mask = None
         self.consumed = True
         return g, m
+
+    def take_strided(self):
+        """``(grad, mask, stride)``; the slot is left empty."""
+        stride, self.stride = self.stride, (1, 1)
+        return self.take() + (stride,)
+
+
+def _scatter_strided(d, stride, shape):
+    """``d`` placed on the pixels ``[::sy, ::sx]`` of a zero tensor of ``shape``."""
+    full = torch.zeros(shape, dtype=d.dtype, device=d.device)
+    full[:, ::stride[0], ::stride[1], :] = d
+    return full
 
 
 class Links:
@@ -290,8 +305,12 @@ class _ConvBnActFn(Function):
         dz = dz.contiguous()
         want_dres = ctx.has_res and ctx.needs_input_grad[4]
         addend = addend_mask = None
+        addend_stride = (1, 1)
         if links.input_grad is not None:
-            addend, addend_mask = links.input_grad.take()
+            addend, addend_mask, addend_stride = links.input_grad.take_strided()
+            if addend is not None and addend_stride != (1, 1) and not (
+                    addend_mask is None and cv.dgrad_coarse_addend_ok(plan, addend_stride)):
+                addend, addend_stride = _scatter_strided(addend, addend_stride, x.shape), (1, 1)
         gate = mask
         if links.output_mask is not None and links.output_mask.mask is not None:
             if mask is not None:
@@ -359,7 +378,8 @@ class _ConvBnActFn(Function):
             if tap is not None and not (tap.armed and cv.dgrad_can_tap(plan)
                                         and (links.input_grad is None or addend is not None)):
                 tap = None
-            gx = cv.conv_dgrad(dy, weight, plan, addend=addend, addend_mask=addend_mask, bn_tap=tap)
+            gx = cv.conv_dgrad(dy, weight, plan, addend=addend, addend_mask=addend_mask, bn_tap=tap,
+                               addend_stride=addend_stride)
             out_slot = links.input_grad_out
             if out_slot is not None and not out_slot.consumed:
                 out_slot.grad, gx = gx, None  # a sibling consumer of x adds it in its own dgrad epilogue
@@ -557,15 +577,13 @@ class _ExpandDualFn(Function):
                                                 mean_s, invstd_s, scale_s, gamma_s)
         gx = gxs = None
         if need[4]:
-            d = cv.conv_dgrad(g, weight_s, plan_s, wd=wds, x2=xs, dbias=qs)
-            if sy == 1 and sx == 1:
-                gxs = d
-            else:
-                gxs = torch.zeros(ctx.full_shape, dtype=BF16, device=x.device)
-                gxs[:, ::sy, ::sx, :] = d
+            gxs = cv.conv_dgrad(g, weight_s, plan_s, wd=wds, x2=xs, dbias=qs)
             slot = links.input_grad_out
             if slot is not None and not slot.consumed:
-                slot.grad, gxs = gxs, None   # the sibling consumer of the block input adds it in its dgrad epilogue
+                # the sibling consumer of the block input adds it, on the shortcut's pixel grid, in its dgrad epilogue
+                slot.grad, slot.stride, gxs = gxs, (sy, sx), None
+            elif (sy, sx) != (1, 1):
+                gxs = _scatter_strided(gxs, (sy, sx), ctx.full_shape)
         if need[0]:
             itap = links.input_tap
             if itap is not None and not (itap.armed and cv.dgrad_can_tap(plan)):

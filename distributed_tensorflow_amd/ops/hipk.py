@@ -35,7 +35,7 @@ class ConvArgs(C.Structure):
         ("bn_y", c_void), ("bn_mean", c_void), ("bn_invstd", c_void), ("bn_scale", c_void), ("bn_shift", c_void),
         ("bn_mask", c_void), ("bn_relu", c_int),
         ("ldo", c_int), ("oscale", c_void), ("stream_out", c_int), ("omask", c_void), ("dbias", c_void), ("bn_gate_store", c_int),
-        ("x2", c_void), ("K1", c_int),
+        ("x2", c_void), ("K1", c_int), ("addend_shy", c_int), ("addend_shx", c_int),
     ]
 
 

@@ -162,6 +162,44 @@ def test_dgrad_masked_addend():
     torch.testing.assert_close(got.float(), want.float(), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("gated", [False, True])
+@pytest.mark.parametrize("case,stride", [((2, 14, 14, 64, 32, 1, 1, 1, 1, "VALID"), (2, 2)),
+                                         ((3, 7, 9, 128, 64, 1, 1, 1, 1, "VALID"), (2, 2)),
+                                         ((2, 12, 10, 256, 128, 1, 1, 1, 1, "VALID"), (2, 1)),
+                                         ((2, 9, 11, 40, 72, 3, 3, 1, 1, "SAME"), (4, 2))])
+def test_dgrad_coarse_grid_addend(case, stride, gated):
+    """An addend on the pixel grid [::sy, ::sx] of the data gradient (the gradient of a strided shortcut) is added in
+    place: same result as scattering it into a zero tensor of the full shape first -- also when the launch stores the
+    gated gradient and emits its per-channel sums."""
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case)
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    assert cv.dgrad_coarse_addend_ok(plan, stride)
+    g = torch.Generator().manual_seed(13)
+    dy = torch.randn(B, plan.oh, plan.ow, Cout, generator=g).bfloat16().cuda()
+    add = torch.randn(B, -(-H // stride[0]), -(-W // stride[1]), Cin, generator=g).bfloat16().cuda()
+    full = torch.zeros(B, H, W, Cin, dtype=torch.bfloat16, device="cuda")
+    full[:, ::stride[0], ::stride[1], :] = add
+
+    def tap():
+        if not gated:
+            return None
+        t = cv.BnBackwardTap()
+        keep = torch.rand(B, H, W, Cin, generator=torch.Generator().manual_seed(3)).cuda() > 0.4
+        t.mask = (keep.view(-1, 8).to(torch.uint8) << torch.arange(8, device="cuda", dtype=torch.uint8)).sum(1).to(torch.uint8)
+        t.relu_mode, t.gate_store = 3, True
+        return t
+
+    t0, t1 = tap(), tap()
+    want = cv.conv_dgrad(dy, w.bfloat16().cuda(), plan, addend=full, bn_tap=t0)
+    got = cv.conv_dgrad(dy, w.bfloat16().cuda(), plan, addend=add, addend_stride=stride, bn_tap=t1)
+    assert torch.equal(got, want)
+    if gated:
+        assert torch.equal(t0.partials, t1.partials)
+    with pytest.raises(ValueError):
+        cv.conv_dgrad(dy, w.bfloat16().cuda(), plan, addend=full, addend_stride=stride)
+
+
 @pytest.mark.parametrize("relu_mode", [0, 2, 3])
 @pytest.mark.parametrize("case", [(2, 14, 14, 64, 32, 1, 1, 1, 1, "VALID"), (3, 9, 11, 40, 72, 3, 3, 1, 1, "SAME"),
                                   (2, 12, 12, 64, 64, 3, 3, 1, 1, "SAME")])
