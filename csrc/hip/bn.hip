@@ -295,6 +295,83 @@ extern "C" int dtfa_bn_apply(const void* y, const void* res, void* z, const floa
 }
 
 // ----------------------------------------------------------------------------
+// z = act(y * scale[c] + shift[c]) with the coefficients made on the spot from the fp64 column sums a statistics
+// epilogue accumulated (ConvArgs::stat_acc): every block derives scale / shift of all C channels into LDS first, block
+// 0 also updates the running statistics.  A forward-only layer of few tiles is then two launches, convolution and
+// this one -- at 10 .. 20 us per convolution the separate finalize kernel was a tenth of the step.
+// ----------------------------------------------------------------------------
+#define BN_SUMS_MAX_C 4096
+template <bool RELU, int U>
+__global__ __launch_bounds__(256) void bn_apply_sums_kernel(const bf16* __restrict__ y, bf16* __restrict__ z,
+                                                             const double* __restrict__ sums, float count, float eps,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                             float momentum, unsigned nvec, int C, int ldz) {
+  extern __shared__ float coef[];  // [2][C]
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double mu = sums[c] / (double)count;
+    double var = sums[C + c] / (double)count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    coef[c] = sc;
+    coef[C + c] = (beta ? beta[c] : 0.f) - (float)mu * sc;
+    if (blockIdx.x == 0 && run_mean != nullptr) {
+      const double unb = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+      run_mean[c] = run_mean[c] * (1.f - momentum) + (float)mu * momentum;
+      run_var[c] = run_var[c] * (1.f - momentum) + (float)unb * momentum;
+    }
+  }
+  __syncthreads();
+  VecCursor cur[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    cur[u] = VecCursor((blockIdx.x * U + u) * 256u + threadIdx.x, gridDim.x * (256u * U), (unsigned)C >> 3);
+  while (cur[0].i < nvec) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = *(const u32x4*)(y + (cur[u].i < nvec ? (size_t)cur[u].i * 8 : 0));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (cur[u].i < nvec) {
+        const int c0 = (int)cur[u].cv << 3;
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2 sc = *(const f32x2*)(coef + c0 + 2 * j), sh = *(const f32x2*)(coef + C + c0 + 2 * j);
+          unsigned w = pack_bf16x2(__builtin_elementwise_fma(unpack_bf16x2(v[u][j]), sc, sh));
+          if (RELU) w = relu_bf16x2(w);
+          o[j] = w;
+        }
+        *(u32x4*)(z + (size_t)cur[u].row * ldz + c0) = o;
+      }
+      cur[u].advance();
+    }
+  }
+}
+
+extern "C" int dtfa_bn_apply_sums(const void* y, void* z, const double* sums, float count, float eps,
+                                  const float* gamma, const float* beta, float* run_mean, float* run_var,
+                                  float momentum, long long M, int C, int ldz, int relu, hipStream_t st) {
+  if (C % 8 || ldz % 8 || ldz < C || C > BN_SUMS_MAX_C) return -1;
+  size_t nvec = (size_t)M * C / 8;
+  if (nvec == 0) return 0;
+  if (nvec >= (1ull << 31)) return -3;
+  constexpr int U = 2;
+  unsigned blocks = (unsigned)((nvec + 256 * U - 1) / (256 * U));
+  if (blocks > BN_MAX_BLOCKS) blocks = BN_MAX_BLOCKS;
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  if (relu)
+    hipLaunchKernelGGL((bn_apply_sums_kernel<true, U>), dim3(blocks), dim3(256), lds, st, (const bf16*)y, (bf16*)z, sums,
+                       count, eps, gamma, beta, run_mean, run_var, momentum, (unsigned)nvec, C, ldz);
+  else
+    hipLaunchKernelGGL((bn_apply_sums_kernel<false, U>), dim3(blocks), dim3(256), lds, st, (const bf16*)y, (bf16*)z, sums,
+                       count, eps, gamma, beta, run_mean, run_var, momentum, (unsigned)nvec, C, ldz);
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
 // Column partial sums.  Thread block = TX channel-groups (8 channels each) x
 // TY row lanes.  MODE 0: x -> (sum x, sum x^2).  MODE 1 (backward):
 //   g = dz * mask,  mask = (zout > 0) [relu 1], (y*scale+shift > 0) [relu 2], a stored bitmask with one

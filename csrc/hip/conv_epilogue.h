@@ -51,6 +51,10 @@ struct ConvArgs {
   // shortcut): output pixel (b, oy, ox) receives addend pixel (b, oy >> shy, ox >> shx) when oy and ox are
   // multiples of the stride (1 << shy, 1 << shx) and nothing otherwise.  0 / 0: the addend has the output's shape.
   int addend_shy, addend_shx;
+  // statistics epilogue: instead of one partial row per tile in ``stats``, add the tile's column sums to
+  // stat_acc[0..Cout) (sum) and stat_acc[Cout..2 Cout) (sum of squares), fp64, zeroed by the caller.  For launches of
+  // few tiles, where a separate reduction kernel per layer costs as much as the layer (see bn_apply_sums).
+  double* stat_acc;
 };
 
 #define MAX_TAPS 64
@@ -259,9 +263,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
     for (int nt = 0; nt < NT; ++nt) {
       const int co = n0 + wc * WN + nt * 32 + colq;
       if (co < p.Cout) {
-        const size_t prow = (size_t)tile_m * 2;
-        p.stats[prow * p.Cout + co] = st1[nt] + xch[((wc * NT + nt) * 32 + colq) * 2];
-        p.stats[(prow + 1) * p.Cout + co] = st2[nt] + xch[((wc * NT + nt) * 32 + colq) * 2 + 1];
+        const float t1 = st1[nt] + xch[((wc * NT + nt) * 32 + colq) * 2];
+        const float t2 = st2[nt] + xch[((wc * NT + nt) * 32 + colq) * 2 + 1];
+        if (p.stat_acc != nullptr) {
+          unsafeAtomicAdd(p.stat_acc + co, (double)t1);
+          unsafeAtomicAdd(p.stat_acc + p.Cout + co, (double)t2);
+        } else {
+          const size_t prow = (size_t)tile_m * 2;
+          p.stats[prow * p.Cout + co] = t1;
+          p.stats[(prow + 1) * p.Cout + co] = t2;
+        }
       }
     }
   }

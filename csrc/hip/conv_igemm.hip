@@ -391,7 +391,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
 template <int BM, int BN, int BK, int NST, int WG = 1>
 static int launch_conv_epi(const ConvArgs& a, hipStream_t stream) {
   if (a.bn_y != nullptr || a.bn_gate_store) return launch_conv<BM, BN, BK, 3, NST, WG>(a, stream);
-  if (a.stats != nullptr) return launch_conv<BM, BN, BK, 1, NST, WG>(a, stream);
+  if (a.stats != nullptr || a.stat_acc != nullptr) return launch_conv<BM, BN, BK, 1, NST, WG>(a, stream);
   if (a.bias != nullptr || a.relu || a.oscale != nullptr || a.ldo != a.Cout)
     return launch_conv<BM, BN, BK, 2, NST, WG>(a, stream);  // (omask rides on relu)
   return launch_conv<BM, BN, BK, 0, NST, WG>(a, stream);
@@ -409,6 +409,9 @@ extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int ns
   if ((a->x2 == nullptr && a->K != a->T * a->Cin) || a->K >= (1 << 16)) return -2;
   if ((long long)a->IH * a->IW >= (1ll << 24) || (long long)a->IH * a->IW * a->Cin >= (1ll << 32)) return -2;
   if (a->stats != nullptr && a->bias != nullptr) return -4;
+  if (a->stat_acc != nullptr && (a->stats != nullptr || a->bias != nullptr || a->relu || a->oscale != nullptr ||
+                                 a->addend != nullptr || a->bn_y != nullptr || a->bn_gate_store || a->ldo != a->Cout))
+    return -4;
   // a residual in the bias / ReLU (forward) epilogue: no bitmask, no statistics
   const bool fwd_residual = a->addend != nullptr && (a->bias != nullptr || a->relu || a->oscale != nullptr);
   if (fwd_residual && (a->addend_mask != nullptr || a->stats != nullptr || a->bn_y != nullptr)) return -4;

@@ -250,8 +250,10 @@ class InceptionV3(nn.Module):
 
     def forward(self, x):
         out = None
-        for _, out in self.endpoints(x, fuse_pools=True):
-            pass
+        # (forward-only batch-statistics layers of few pixels keep their statistics in accumulators: F.stat_scope)
+        with F.stat_scope(x.device):
+            for _, out in self.endpoints(x, fuse_pools=True):
+                pass
         return out
 
 

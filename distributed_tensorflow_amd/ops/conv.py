@@ -171,6 +171,9 @@ def _env_tile(name: str):
     return tuple(int(t) for t in v.split(","))
 
 
+_SMALL_GRID_TILES = int(os.environ.get("DTFA_SMALL_GRID_TILES", "256"))
+
+
 def pick_fwd_tile(M: int, cout: int, K: int, dense: bool = True) -> Tuple[int, int, int, int]:
     """(BM, BN, BK, LDS stages) of the implicit-GEMM kernel.  Chosen from a sweep over the ResNet-50 layer shapes
     and Inception-v3 layer shapes on MI355X (tools/sweep_conv.py, profiles/tile_sweep_b256.md); a 256-row
@@ -194,6 +197,11 @@ def pick_fwd_tile(M: int, cout: int, K: int, dense: bool = True) -> Tuple[int, i
     tiles = -(-M // bm) * -(-cout // bn)
     if bn == 64 and tiles < 512:
         bm = 64
+    if tiles < _SMALL_GRID_TILES and (bm, bn) != (64, 64):
+        # fewer tiles than CUs (the 17x17 / 8x8 Inception layers at batch 32, dense layers): the launch is a chain of
+        # k-steps on a mostly idle chip, so the smallest tile -- the most workgroups, the shortest k-step -- wins
+        # (measured at batch 32: 17x17 1x7 192->192 23.2 -> 15.2 us, 8x8 3x3 448->384 55.7 -> 32.3 us)
+        return 64, 64, (64 if K >= 256 else 32), 2
     if _WIDE and bn == 128 and K >= _WIDE_MIN_K and tiles >= _WIDE_MIN_TILES:
         # 256-row macro tile: two 128-row wave groups share one weight tile (fewer L2 -> LDS bytes per FLOP)
         return 256, 128, _WIDE_BK, (2 if _WIDE_BK == 64 else 3)
@@ -250,7 +258,8 @@ STREAM_OUT_BYTES = int(os.environ.get("DTFA_CONV_STREAM_OUT_BYTES", str(256 << 2
 
 def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, osx, oy0, ox0, isy, isx, B,
                   cin_magic, bias=None, relu=False, stats=False, addend=None, zero_taps=False, addend_mask=None,
-                  bn_tap=None, oscale=None, ldo=0, omask=None, dbias=None, x2=None, addend_shift=(0, 0)):
+                  bn_tap=None, oscale=None, ldo=0, omask=None, dbias=None, x2=None, addend_shift=(0, 0),
+                  stat_acc=None):
     M = B * oyn * oxn
     K = T * cin + (x2.shape[-1] if x2 is not None else 0)
     dense_out = osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow
@@ -275,6 +284,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     a.stream_out = 1 if M * cout * 2 >= STREAM_OUT_BYTES else 0
     a.K1 = T * cin
     a.addend_shy, a.addend_shx = addend_shift
+    a.stat_acc = hipk.ptr(stat_acc)
     a.zero = hipk.zero_page(x.device).data_ptr()
     a.taps = taps.data_ptr()
     a.IH, a.IW, a.Cin = ih, iw, cin
@@ -299,8 +309,13 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[torch.Tensor] = None,
              relu: bool = False, want_stats: bool = False, scale: Optional[torch.Tensor] = None,
              out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-             mask_out: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None):
+             mask_out: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None,
+             stat_acc: Optional[torch.Tensor] = None):
     """x [B,IH,IW,Cin] bf16, w [Cout,KH,KW,Cin] bf16 -> (y [B,OH,OW,Cout] bf16, stats partials or None).
+
+    ``stat_acc`` (fp64 [2 * Cout], zeroed by the caller; excludes every other epilogue option): the column sums and
+    sums of squares of the output are *added* to it by atomics -- for launches of few tiles, whose consumer
+    (``kernels.bn_apply_sums``) then needs no reduction pass over partial rows.
 
     Pointwise layers: with ``x2`` ([B,OH,OW,C2] bf16) the reduction runs over ``[x | x2]`` and ``w`` is
     ``[Cout, Cin + C2]`` (two 1x1 convolutions summed in one GEMM).
@@ -341,6 +356,13 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
             raise ValueError("residual needs the output's shape and the bias / scale epilogue")
     if B * plan.oh * plan.ow >= 1 << 31:
         raise ValueError("too many output pixels for 32-bit row indices")
+    if stat_acc is not None:
+        if (stat_acc.dtype != torch.float64 or stat_acc.numel() != 2 * plan.cout or not stat_acc.is_contiguous()
+                or stat_acc.device != x.device):
+            raise ValueError("stat_acc must hold 2 * Cout contiguous fp64 values on the input's device")
+        if (want_stats or bias is not None or scale is not None or relu or residual is not None or out is not None
+                or mask_out is not None):
+            raise ValueError("stat_acc excludes the other epilogue options")
     ldo = 0
     if out is None:
         y = torch.empty((B, plan.oh, plan.ow, plan.cout), dtype=torch.bfloat16, device=x.device)
@@ -357,8 +379,39 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
             raise ValueError("mask_out needs a ReLU, a dense output and numel / 8 bytes")
     part = _launch_igemm(x, w, y, plan.fwd_taps, plan.T, plan.ih, plan.iw, plan.cin, plan.oh, plan.ow, plan.cout,
                          plan.oh, plan.ow, 1, 1, 0, 0, plan.sy, plan.sx, B, plan.cin_magic, bias, relu, want_stats,
-                         addend=residual, zero_taps=plan.is_pointwise, oscale=scale, ldo=ldo, omask=mask_out, x2=x2)
+                         addend=residual, zero_taps=plan.is_pointwise, oscale=scale, ldo=ldo, omask=mask_out, x2=x2,
+                         stat_acc=stat_acc)
     return y, part
+
+
+# --------------------------------------------------------------------------
+# dense layers over a handful of rows (csrc/hip/dense_skinny.hip)
+# --------------------------------------------------------------------------
+SKINNY_MAX_ROWS = int(os.environ.get("DTFA_SKINNY_MAX_ROWS", "128"))
+
+
+def dense_skinny_ok(rows: int, n_in: int, n_out: int) -> bool:
+    return 0 < rows <= SKINNY_MAX_ROWS and n_in % 16 == 0 and n_out % 8 == 0
+
+
+def dense_skinny(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """``act(x [M, K] @ w [N, K]^T + bias)`` for few rows: the reduction, not the output, is spread over the waves."""
+    hipk.require(x, torch.bfloat16, "x")
+    hipk.require(w, torch.bfloat16, "w")
+    M, Kd = x.shape
+    N = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != Kd or Kd % 16 or N % 8:
+        raise ValueError("dense_skinny: w must be [N, K] with K %% 16 == 0 and N %% 8 == 0, got %s" % (tuple(w.shape),))
+    if bias is not None:
+        hipk.require(bias, torch.float32, "bias")
+        if bias.numel() != N:
+            raise ValueError("bias size")
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    a = hipk.SkinnyArgs()
+    a.x, a.w, a.bias, a.y = x.data_ptr(), w.data_ptr(), hipk.ptr(bias), y.data_ptr()
+    a.M, a.N, a.K, a.relu = M, N, Kd, 1 if relu else 0
+    hipk.check(hipk.lib().dtfa_dense_skinny(C.byref(a), hipk.stream()), "dense_skinny")
+    return y
 
 
 # --------------------------------------------------------------------------
@@ -644,7 +697,6 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
         raise ValueError("too many pixels for 32-bit indices")
     bmw, bnw, bkp, splits = pick_wgrad_tile(M, plan.cout, plan.K, plan.cin)
     n = plan.cout * plan.K
-    slab = hipk.workspace(x.device, splits * n * 4)
     if out is None:
         out = torch.empty((plan.cout, plan.kh, plan.kw, plan.cin), dtype=torch.float32, device=x.device)
         accumulate = False
@@ -652,6 +704,9 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
         raise ValueError("bad wgrad output buffer")
     if out.dtype == torch.bfloat16 and accumulate:
         raise ValueError("accumulation needs an fp32 gradient buffer")
+    # an unsplit reduction (few pixels: dense layers at small batch) writes the fp32 gradient in place
+    direct = splits == 1 and out.dtype == torch.float32 and not accumulate
+    slab = out if direct else hipk.workspace(x.device, splits * n * 4)
     L = hipk.lib()
     a = hipk.WgradArgs()
     a.x, a.dy, a.slab = x.data_ptr(), dy.data_ptr(), slab.data_ptr()
@@ -663,6 +718,8 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
     a.T, a.M, a.K = plan.T, M, plan.K
     a.cin_magic = plan.cin_magic
     hipk.check(L.dtfa_conv_wgrad(C.byref(a), bmw, bnw, bkp, splits, hipk.stream()), "conv_wgrad")
+    if direct:
+        return out
     f32 = out.data_ptr() if out.dtype == torch.float32 else None
     b16 = out.data_ptr() if out.dtype == torch.bfloat16 else None
     hipk.check(L.dtfa_wgrad_reduce(slab.data_ptr(), splits, n, f32, b16, 1 if accumulate else 0, hipk.stream()),

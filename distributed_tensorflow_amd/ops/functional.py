@@ -262,6 +262,76 @@ def run_branches(x: torch.Tensor, jobs) -> None:
 
 
 # ----------------------------------------------------------------------------
+# batch statistics of small forward-only layers: fp64 accumulators instead of partial rows + a reduction launch
+# ----------------------------------------------------------------------------
+# A frozen trunk evaluated with batch statistics at a small batch (the Inception-v3 trunk at batch 32) is ~94 layers
+# of 10 .. 20 us convolutions; reducing each layer's partial statistics rows in a kernel of its own was a tenth of
+# the step.  Inside a ``stat_scope`` such layers (at most STAT_ACC_MAX_ROWS output pixels, nothing requiring grad)
+# let the convolution add its column sums to a slice of one zeroed fp64 buffer and the normalisation kernel derive
+# its coefficients from the slice: two launches per layer, and one fill per forward pass.
+STAT_ACC_MAX_ROWS = int(os.environ.get("DTFA_STAT_ACC_MAX_ROWS", str(1 << 16)))
+_STAT_CHUNK = 1 << 15   # fp64 values per buffer (256 KB); Inception-v3 needs ~2 x 17 k
+
+
+class _StatScope:
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+        self.used = 0
+
+    def take(self, n: int) -> torch.Tensor:
+        if self.buf is None or self.used + n > self.buf.numel():
+            self.buf = torch.zeros(max(_STAT_CHUNK, n), dtype=torch.float64, device=self.device)
+            self.used = 0
+        out = self.buf[self.used:self.used + n]
+        self.used += (n + 1) & ~1   # keep slices 16-byte aligned
+        return out
+
+
+_stat_scope: Optional[_StatScope] = None
+
+
+class stat_scope:
+    """Context manager: forward-only batch-statistics layers of few output pixels inside it use accumulator slices
+    (see above).  Re-entrant use keeps the outer scope; a no-op off the device."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.mine = False
+
+    def __enter__(self):
+        global _stat_scope
+        if _stat_scope is None and self.device.type == "cuda" and STAT_ACC_MAX_ROWS > 0:
+            _stat_scope, self.mine = _StatScope(self.device), True
+        return self
+
+    def __exit__(self, *exc):
+        global _stat_scope
+        if self.mine:
+            _stat_scope, self.mine = None, False
+        return False
+
+
+def _stat_slice(plan, rows: int):
+    """An accumulator slice for a layer of ``rows`` output pixels, or None (no scope / too many rows / too wide)."""
+    if _stat_scope is None or rows > STAT_ACC_MAX_ROWS or plan.cout > K.BN_SUMS_MAX_C:
+        return None
+    return _stat_scope.take(2 * plan.cout)
+
+
+def _conv_bn_forward_only(x, weight, gamma, beta, plan, run_mean, run_var, eps, momentum, relu, out):
+    """Batch-statistics ``act(bn(conv(x)))`` with nothing kept for a backward pass."""
+    rows = x.shape[0] * plan.oh * plan.ow
+    acc = _stat_slice(plan, rows)
+    if acc is not None:
+        y, _ = cv.conv_fwd(x, weight, plan, stat_acc=acc)
+        return K.bn_apply_sums(y, acc, rows, eps, gamma, beta, run_mean, run_var, momentum, relu, out=out)
+    y, part = cv.conv_fwd(x, weight, plan, want_stats=True)
+    _, _, scale, shift = K.bn_finalize(part, rows, eps, gamma, beta, run_mean, run_var, momentum)
+    return K.bn_apply(y, scale, shift, relu, None, out=out)
+
+
+# ----------------------------------------------------------------------------
 # conv + batch-norm (+ residual) (+ ReLU)
 # ----------------------------------------------------------------------------
 class _ConvBnActFn(Function):
@@ -701,12 +771,10 @@ def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, e
         if not training:
             scale, shift = eval_coeffs or K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
             return cv.conv_fwd(x, weight, plan, bias=shift, relu=relu, scale=scale, out=out, residual=residual)[0]
-        y, part = cv.conv_fwd(x, weight, plan, want_stats=training)
-        if training:
-            _, _, scale, shift = K.bn_finalize(part, y.numel() // plan.cout, eps, gamma, beta, run_mean, run_var,
-                                               momentum)
-        else:
-            scale, shift = eval_coeffs or K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
+        if residual is None:
+            return _conv_bn_forward_only(x, weight, gamma, beta, plan, run_mean, run_var, eps, momentum, relu, out)
+        y, part = cv.conv_fwd(x, weight, plan, want_stats=True)
+        _, _, scale, shift = K.bn_finalize(part, y.numel() // plan.cout, eps, gamma, beta, run_mean, run_var, momentum)
         return K.bn_apply(y, scale, shift, relu, residual, out=out)
     if not _use_hip(x):
         y = ref.conv2d(x, weight, (sy, sx), pads)
@@ -722,6 +790,8 @@ def conv_bn_act(x, weight, gamma, beta, run_mean, run_var, *, stride, padding, e
         scale, shift = eval_coeffs or K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
         res = residual.contiguous() if residual is not None else None
         return cv.conv_fwd(x, weight, plan, bias=shift, relu=relu, scale=scale, residual=res)[0]
+    if training and residual is None and links is None and not _needs_grad(x, weight, gamma, beta):
+        return _conv_bn_forward_only(x, weight, gamma, beta, plan, run_mean, run_var, eps, momentum, relu, None)
     links = links if links is not None else _NO_LINKS
     if links.input_grad is not None and (plan.dgrad_needs_zero or not x.requires_grad):
         raise ValueError("input_grad needs an input that requires grad and a dgrad that writes every pixel")
@@ -761,7 +831,13 @@ def expand_dual(x, main, x_in, shortcut, links=None):
 class _ConvFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, plan, relu, params):
-        y, _ = cv.conv_fwd(x, weight, plan, bias=bias, relu=relu)
+        rows = x.shape[0] * x.shape[1] * x.shape[2]
+        if plan.is_pointwise and cv.dense_skinny_ok(rows, plan.cin, plan.cout):
+            # a dense layer (or 1x1 convolution) over a handful of rows
+            y = cv.dense_skinny(x.reshape(rows, plan.cin), weight.reshape(plan.cout, plan.cin), bias, relu)
+            y = y.view(x.shape[0], x.shape[1], x.shape[2], plan.cout)
+        else:
+            y, _ = cv.conv_fwd(x, weight, plan, bias=bias, relu=relu)
         ctx.plan, ctx.relu, ctx.params = plan, relu, params
         ctx.save_for_backward(x, weight, y if relu else None)
         return y

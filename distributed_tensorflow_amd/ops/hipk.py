@@ -35,7 +35,7 @@ class ConvArgs(C.Structure):
         ("bn_y", c_void), ("bn_mean", c_void), ("bn_invstd", c_void), ("bn_scale", c_void), ("bn_shift", c_void),
         ("bn_mask", c_void), ("bn_relu", c_int),
         ("ldo", c_int), ("oscale", c_void), ("stream_out", c_int), ("omask", c_void), ("dbias", c_void), ("bn_gate_store", c_int),
-        ("x2", c_void), ("K1", c_int), ("addend_shy", c_int), ("addend_shx", c_int),
+        ("x2", c_void), ("K1", c_int), ("addend_shy", c_int), ("addend_shx", c_int), ("stat_acc", c_void),
     ]
 
 
@@ -56,6 +56,11 @@ class WgradArgs(C.Structure):
         ("cin_magic", C.c_uint), ("ktiles_per_split", c_int), ("splits", c_int),
         ("step_b", c_int), ("step_y", c_int), ("step_x", c_int),
     ]
+
+
+class SkinnyArgs(C.Structure):
+    _fields_ = [("x", c_void), ("w", c_void), ("bias", c_void), ("y", c_void), ("M", c_int), ("N", c_int),
+                ("K", c_int), ("relu", c_int)]
 
 
 class PoolArgs(C.Structure):
@@ -86,6 +91,7 @@ class _Sigs:
     dtfa_conv_igemm = [C.POINTER(ConvArgs), c_int, c_int, c_int, c_int, c_void]
     dtfa_conv_pro = [C.POINTER(ConvArgs), C.POINTER(ProArgs), c_int, c_int, c_int, c_void]
     dtfa_conv_stats_rows = [c_int, c_int]
+    dtfa_dense_skinny = [C.POINTER(SkinnyArgs), c_void]
     dtfa_conv_wgrad = [C.POINTER(WgradArgs), c_int, c_int, c_int, c_int, c_void]
     dtfa_wgrad_reduce = [c_void, c_int, c_ll, c_void, c_void, c_int, c_void]
     dtfa_partial_reduce = [c_void, c_void, c_int, c_int, c_int, c_int, c_void]
@@ -93,6 +99,8 @@ class _Sigs:
                         c_void, c_void, c_float, c_void]
     dtfa_bn_eval_coeffs = [c_int, c_float, c_void, c_void, c_void, c_void, c_void, c_void, c_void]
     dtfa_bn_apply = [c_void, c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_int, c_void]
+    dtfa_bn_apply_sums = [c_void, c_void, c_void, c_float, c_float, c_void, c_void, c_void, c_void, c_float, c_ll, c_int,
+                          c_int, c_int, c_void]
     dtfa_col_partials_rows = [c_ll, c_int]
     dtfa_bn_stats_partials = [c_void, c_void, c_ll, c_int, c_void]
     dtfa_bn_bwd_partials = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_void]

@@ -200,6 +200,34 @@ def bn_apply(y: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bo
     return (z, mask) if want_mask else z
 
 
+BN_SUMS_MAX_C = 4096
+
+
+def bn_apply_sums(y: torch.Tensor, sums: torch.Tensor, count: int, eps: float, gamma, beta, run_mean, run_var,
+                  momentum: float, relu: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(bn(y))`` with batch statistics given as fp64 column sums ``sums`` = [sum y | sum y^2] (2C values, as the
+    convolution's statistics epilogue accumulates them): coefficients, running-statistics update and the elementwise
+    pass in one launch.  ``out`` may be a channel slice of a wider NHWC tensor."""
+    hipk.require(y, BF16, "y")
+    M, Cc = _as2d(y)
+    if sums.dtype != torch.float64 or sums.numel() != 2 * Cc or not sums.is_contiguous() or Cc > BN_SUMS_MAX_C:
+        raise ValueError("column sums must be %d contiguous fp64 values" % (2 * Cc))
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (run_mean, "running_mean"), (run_var, "running_var")):
+        if t is not None:
+            hipk.require(t, F32, nm)
+            if t.numel() != Cc:
+                raise ValueError("%s has %d elements, expected %d" % (nm, t.numel(), Cc))
+    if out is None:
+        z, ldz = torch.empty_like(y), Cc
+    else:
+        z, ldz = out, channel_slice_pitch(out, y)
+    hipk.check(hipk.lib().dtfa_bn_apply_sums(y.data_ptr(), z.data_ptr(), sums.data_ptr(), float(count), float(eps),
+                                             hipk.ptr(gamma), hipk.ptr(beta), hipk.ptr(run_mean), hipk.ptr(run_var),
+                                             float(momentum), M, Cc, ldz, 1 if relu else 0, hipk.stream()),
+               "bn_apply_sums")
+    return z
+
+
 def _bn_bwd_mode(dz, y, zout, relu, scale, shift, mask):
     hipk.require(dz, BF16, "dz")
     hipk.require(y, BF16, "y")

@@ -234,3 +234,45 @@ def test_dgrad_emits_bn_backward_partials(case, relu_mode):
     got = tap.partials.double().sum(0)
     torch.testing.assert_close(got[0], want1, rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(got[1], want2, rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("case", [(32, 17, 17, 192, 192, 1, 7, 1, 1, "SAME"), (32, 8, 8, 448, 384, 3, 3, 1, 1, "SAME"),
+                                  (4, 35, 35, 48, 64, 5, 5, 1, 1, "SAME"), (3, 9, 11, 40, 72, 3, 3, 2, 2, "VALID")])
+def test_statistics_accumulated_by_atomics_match_partial_rows(case):
+    """``stat_acc``: the column sums land in one fp64 accumulator (added by every tile, from every XCD) and equal the
+    sum of the partial rows of the ordinary statistics epilogue; the output tensor is the same."""
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case)
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    xb, wb = x.bfloat16().cuda(), w.bfloat16().cuda()
+    y0, part = cv.conv_fwd(xb, wb, plan, want_stats=True)
+    acc = torch.zeros(2 * Cout, dtype=torch.float64, device="cuda")
+    y1, none = cv.conv_fwd(xb, wb, plan, stat_acc=acc)
+    assert none is None and torch.equal(y0, y1)
+    want = part.double().sum(0).reshape(-1)
+    torch.testing.assert_close(acc, want, rtol=1e-6, atol=1e-4)
+    # accumulators add up over launches
+    cv.conv_fwd(xb, wb, plan, stat_acc=acc)
+    torch.testing.assert_close(acc, 2 * want, rtol=1e-6, atol=2e-4)
+    with pytest.raises(ValueError):
+        cv.conv_fwd(xb, wb, plan, stat_acc=acc, want_stats=True)
+
+
+@pytest.mark.parametrize("M,N,K,relu,bias", [(32, 1024, 2048, True, True), (1, 8, 1024, False, True), (5, 40, 48, True, False),
+                                             (128, 1008, 2048, False, True), (33, 72, 80, True, True), (7, 2048, 16, False, False)])
+def test_dense_skinny_matches_fp32_reference(M, N, K, relu, bias):
+    """Few-row dense layer (reduction spread over the waves of a workgroup) against an fp32 matmul of the same bf16
+    operands."""
+    g = torch.Generator().manual_seed(M * 31 + N)
+    x = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().cuda()
+    b = torch.randn(N, generator=g).cuda() if bias else None
+    assert cv.dense_skinny_ok(M, K, N)
+    got = cv.dense_skinny(x, w, b, relu)
+    want = x.float() @ w.float().t()
+    if bias:
+        want = want + b
+    if relu:
+        want = torch.relu(want)
+    assert got.shape == (M, N) and got.dtype == torch.bfloat16
+    torch.testing.assert_close(got.float(), want, rtol=1e-2, atol=1e-2)

@@ -275,3 +275,39 @@ def test_bn_relu_maxpool_fused_matches_unfused(shape, k, stride, pads, relu):
     torch.testing.assert_close(dg, dg_ref, rtol=2e-2, atol=2e-2 * dg_ref.abs().max().item())
     torch.testing.assert_close(db, db_ref, rtol=2e-2, atol=2e-2 * db_ref.abs().max().item())
     assert (dy.float() - dy_ref.float()).abs().max().item() <= 3e-2 * dy_ref.float().abs().max().item()
+
+
+@pytest.mark.parametrize("shape,relu,sliced", [((32, 17, 17, 192), True, True), ((32, 8, 8, 448), True, False),
+                                               ((5, 7, 9, 48), False, True), ((2, 3, 3, 2048), True, False)])
+def test_bn_apply_from_column_sums_matches_finalize_then_apply(shape, relu, sliced):
+    """One launch (coefficients from fp64 column sums, running statistics, elementwise pass) against the
+    partial rows -> finalize -> apply sequence."""
+    g = torch.Generator().manual_seed(21)
+    y = (torch.randn(*shape, generator=g) * 1.5 + 0.3).bfloat16().cuda()
+    Cc = shape[-1]
+    M = y.numel() // Cc
+    gamma = (torch.rand(Cc, generator=g) + 0.5).cuda()
+    beta = (torch.randn(Cc, generator=g) * 0.2).cuda()
+    rm0, rv0 = torch.randn(Cc, generator=g).cuda() * 0.1, (torch.rand(Cc, generator=g) + 0.5).cuda()
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    part = K.bn_stats_partials(y)
+    _, _, scale, shift = K.bn_finalize(part, M, 1e-3, gamma, beta, rm0, rv0, 0.1)
+    yf = y.double().reshape(-1, Cc)
+    sums = torch.cat((yf.sum(0), (yf * yf).sum(0))).contiguous()
+
+    def target():
+        if not sliced:
+            return None, None
+        buf = torch.full(shape[:-1] + (Cc + 24,), 7.0, dtype=torch.bfloat16, device="cuda")
+        return buf, buf[..., 8:8 + Cc]
+
+    b0, o0 = target()
+    b1, o1 = target()
+    want = K.bn_apply(y, scale, shift, relu, None, out=o0)
+    got = K.bn_apply_sums(y, sums, M, 1e-3, gamma, beta, rm1, rv1, 0.1, relu, out=o1)
+    torch.testing.assert_close(got.float(), want.float(), rtol=2e-2, atol=2e-2)
+    assert (got.float() - want.float()).abs().mean() < 1e-3
+    torch.testing.assert_close(rm1, rm0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv1, rv0, rtol=1e-4, atol=1e-6)
+    if sliced:
+        assert torch.equal(b1[..., :8], b0[..., :8]) and torch.equal(b1[..., 8 + Cc:], b0[..., 8 + Cc:])

@@ -275,3 +275,24 @@ def test_resnet_pixel_pair_stem_equals_the_8_channel_stem():
     assert (gs8[..., :3] - gs4[..., :3]).norm().item() <= 5e-2 * gs8[..., :3].norm().item()
     for n in ("blocks.0.conv1.weight", "blocks.15.conv3.weight", "fc.weight"):
         assert (g8[n] - g4[n]).norm().item() <= 8e-2 * g8[n].norm().item() + 1e-6, n
+
+
+def test_inception_trunk_statistics_in_accumulators_match_partial_rows(monkeypatch):
+    """Inside ``F.stat_scope`` the forward-only batch-statistics layers of few pixels keep their statistics in fp64
+    accumulators (no reduction launch per layer); features and running statistics match the partial-rows path."""
+    torch.manual_seed(0)
+    x, _ = _images(4, 299, seed=7)
+    x = x.cuda().bfloat16()
+    outs, stats = [], []
+    for rows in (1 << 16, 0):
+        torch.manual_seed(1)
+        model = build_model("inception_v3_head", device="cuda").train()
+        monkeypatch.setattr(F, "STAT_ACC_MAX_ROWS", rows)
+        with torch.no_grad(), F.stat_scope(x.device):
+            outs.append(dict(model.trunk.endpoints(x, fuse_pools=True))["Mixed_7c"].float())
+        stats.append(torch.cat([m.running_var.flatten() for m in model.trunk.modules() if hasattr(m, "running_var")]))
+    a, b = outs
+    # 94 layers deep in bf16: a last-bit difference in a coefficient moves a few activations by one rounding step
+    assert (a - b).abs().mean() <= 2e-3 * b.abs().mean() + 1e-4
+    torch.testing.assert_close(a, b, rtol=5e-2, atol=5e-2)
+    torch.testing.assert_close(stats[0], stats[1], rtol=1e-3, atol=1e-5)
