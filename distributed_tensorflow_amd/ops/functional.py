@@ -270,7 +270,7 @@ def run_branches(x: torch.Tensor, jobs) -> None:
 # let the convolution add its column sums to a slice of one zeroed fp64 buffer and the normalisation kernel derive
 # its coefficients from the slice: two launches per layer, and one fill per forward pass.
 STAT_ACC_MAX_ROWS = int(os.environ.get("DTFA_STAT_ACC_MAX_ROWS", str(1 << 16)))
-_STAT_CHUNK = 1 << 15   # fp64 values per buffer (256 KB); Inception-v3 needs ~2 x 17 k
+_STAT_CHUNK = 1 << 16   # fp64 values per buffer (512 KB); Inception-v3 needs ~2 x 17 k
 
 
 class _StatScope:
