@@ -23,11 +23,23 @@ def _grads_by_name(model):
     return {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
 
 
-@pytest.mark.parametrize("name,size,batch", [("flower_cnn", 64, 16), ("resnet50", 96, 16)])
-def test_forward_backward_matches_cpu_reference(name, size, batch):
+@pytest.mark.parametrize("name,size,batch,damp", [("flower_cnn", 64, 16, 1.0), ("resnet50", 96, 16, 0.1),
+                                                   ("resnet50", 128, 32, 0.1)])
+def test_forward_backward_matches_cpu_reference(name, size, batch, damp):
+    """Loss and every parameter gradient of a training step against fp32 CPU autograd.
+
+    ``damp`` scales the last batch-norm scale of every residual branch (the usual near-zero initialisation of that
+    scale).  At 1.0 a random 50-layer network at these sizes is chaotic in bf16: *any* bf16 evaluation -- PyTorch's own
+    GPU ops included -- returns gradients uncorrelated with the fp32 ones (relative error 1.3 over the whole gradient),
+    and a comparison proves nothing.  Damped, the same comparison is sharp: whole-gradient error 0.09 .. 0.12, loss
+    within 0.002 (tools/dev/diag_model_tol.py prints the calibration)."""
     torch.manual_seed(0)
     kw = {"dropout_rate": 0.0} if name == "flower_cnn" else {"zero_init_residual": False}
     cpu = build_model(name, device="cpu", **kw).train()
+    if damp != 1.0:
+        for n, p in cpu.named_parameters():
+            if n.endswith("conv3.gamma"):
+                p.data.mul_(damp)
     # round weights to bf16 so that both paths start from identical values
     for p in cpu.parameters():
         if p.dim() > 1:
@@ -46,15 +58,15 @@ def test_forward_backward_matches_cpu_reference(name, size, batch):
 
     loss_c, logit_c = run(cpu, xb.float(), y)
     loss_g, logit_g = run(gpu, xb.cuda(), y.cuda())
-    # calibration: the same network through PyTorch's own bf16 GPU ops.  bf16 activations
-    # (ReLU-mask flips, batch-norm cancellation) put both bf16 paths the same distance from
-    # the fp32 oracle; the HIP path must not be further away than the library path.
+    # calibration: the same network through PyTorch's own bf16 GPU ops.  bf16 activations (ReLU-mask flips,
+    # batch-norm cancellation) put both bf16 paths the same distance from the fp32 oracle; the HIP path must not be
+    # further away than the library path (measured: loss deviations <= 0.0015 on both, per-tensor errors within
+    # 1.25 x the library's, whole-gradient error 0.95 .. 1.06 x the library's).
     gpu_ref = cast_for_device(copy.deepcopy(cpu), "cuda").train()
     with F.reference_mode():
         loss_r, _ = run(gpu_ref, xb.cuda(), y.cuda())
     lib_dev = abs(loss_c.item() - loss_r.item())
-    # (the last stage normalises over batch * 3 * 3 values only, so a few percent of loss noise is inherent)
-    assert abs(loss_c.item() - loss_g.item()) <= 1.5 * lib_dev + 0.08 * max(1.0, abs(loss_c.item()))
+    assert abs(loss_c.item() - loss_g.item()) <= 1.5 * lib_dev + 0.005
     gc, gg, gr = _grads_by_name(cpu), _grads_by_name(gpu), _grads_by_name(gpu_ref)
     assert gc.keys() == gg.keys()
     bad = []
@@ -63,9 +75,14 @@ def test_forward_backward_matches_cpu_reference(name, size, batch):
         denom = a.norm().item() + 1e-6
         rel = (a - gg[n]).norm().item() / denom
         rel_lib = (a - gr[n]).norm().item() / denom
-        if rel > 1.5 * rel_lib + 0.03:
+        if rel > 1.3 * rel_lib + 0.02:
             bad.append((n, rel, rel_lib))
     assert not bad, bad[:10]
+    whole = lambda g: torch.cat([g[n].flatten() for n in gc])
+    vc, vg, vr = whole(gc), whole(gg), whole(gr)
+    err_hip, err_lib = ((vc - vg).norm() / vc.norm()).item(), ((vc - vr).norm() / vc.norm()).item()
+    assert err_lib < 0.2, err_lib   # the comparison is in its meaningful regime
+    assert err_hip <= 1.1 * err_lib + 0.01, (err_hip, err_lib)
 
 
 @pytest.mark.parametrize("name,size,batch", [("flower_cnn", 64, 8), ("resnet50", 96, 8), ("inception_v3_head", 299, 2)])
