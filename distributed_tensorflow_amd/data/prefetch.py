@@ -29,7 +29,9 @@ class DevicePrefetcher:
         self._produce = produce
         self._stream = torch.cuda.Stream(device=self.device)
         self._pool = cf.ThreadPoolExecutor(1, thread_name_prefix="dtfa-batch")
-        self._queue = [self._pool.submit(self._run) for _ in range(max(1, depth))]
+        self._depth = max(1, depth)
+        self._ahead = True
+        self._queue = [self._pool.submit(self._run) for _ in range(self._depth)]
 
     def _run(self):
         torch.cuda.set_device(self.device)
@@ -37,10 +39,22 @@ class DevicePrefetcher:
             out = tuple(self._produce())
             return out, self._stream.record_event()
 
+    def set_ahead(self, ahead: bool) -> None:
+        """``False``: stop preparing batches ahead; the ones already queued are handed out in order, after that
+        ``next()`` runs the producer in line on the caller's stream (same sequence of producer calls).  Worth it once
+        a producer has nothing left to overlap -- e.g. every image comes from the device-resident cache, so a batch
+        is a few kernel launches and the helper thread only adds hand-over cost.  ``True`` resumes."""
+        self._ahead = bool(ahead)
+
     def next(self):
         """The oldest prepared batch (waits for the helper thread if it is still at work) and starts another one."""
+        if not self._queue:
+            if not self._ahead:
+                return tuple(self._produce())
+            self._queue = [self._pool.submit(self._run) for _ in range(self._depth)]
         tensors, event = self._queue.pop(0).result()
-        self._queue.append(self._pool.submit(self._run))
+        if self._ahead:
+            self._queue.append(self._pool.submit(self._run))
         main = torch.cuda.current_stream(self.device)
         main.wait_event(event)
         for t in tensors:

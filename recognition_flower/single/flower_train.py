@@ -145,6 +145,7 @@ def main(argv):
         prefetcher = DevicePrefetcher(lambda: next_batch(train, batch_size), device, depth=FLAGS.prefetch_depth)
     t0 = time.time()
     done = False
+    misses_seen = 0
     with sess:
         for epoch in range(FLAGS.n_epochs):
             print("Epoch", epoch, end="\n")
@@ -156,6 +157,11 @@ def main(argv):
                     break
             if done:
                 break
+            if prefetcher is not None and image_cache is not None:
+                # an epoch served entirely from the device-resident image cache leaves the helper thread nothing to
+                # overlap (a batch is then a few kernel launches): prepare batches in line until files miss again
+                missed, misses_seen = image_cache.misses - misses_seen, image_cache.misses
+                prefetcher.set_ahead(missed > 0)
         if prefetcher is not None:
             prefetcher.close()
         if test:

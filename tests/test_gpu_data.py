@@ -161,6 +161,32 @@ def test_device_prefetcher_hands_over_batches_in_order():
         DevicePrefetcher(produce, "cpu")
 
 
+def test_device_prefetcher_switches_between_ahead_and_in_line_without_losing_order():
+    """``set_ahead(False)`` drains the queued batches and then runs the producer in line (no batch produced that is
+    not handed out); ``set_ahead(True)`` resumes; the sequence of batches is the producer's throughout."""
+    from distributed_tensorflow_amd.data.prefetch import DevicePrefetcher
+
+    state = {"k": 0}
+
+    def produce():
+        k = state["k"]
+        state["k"] += 1
+        return (torch.full((1024,), float(k), device="cuda"),)
+
+    pf = DevicePrefetcher(produce, "cuda", depth=3)
+    seen = []
+    for step in range(20):
+        if step == 5:
+            pf.set_ahead(False)
+        if step == 12:
+            assert state["k"] == 12   # in line: exactly as many produced as consumed
+            pf.set_ahead(True)
+        (x,) = pf.next()
+        seen.append(int(x[0].item()))
+    pf.close()
+    assert seen == list(range(20))
+
+
 def test_decoded_image_cache_serves_pixels_from_the_device(tmp_path):
     """Files are read and entropy-decoded once; later batches point the resize kernel at the cached pixels
     (offsets relative to another buffer, modulo 2^64) and produce identical network inputs."""

@@ -4,7 +4,7 @@ batch prepared during the step (``--prefetch``) and in line with it, decoded ima
 (``--image_cache_gb``) and decoded afresh every time.  The dataset is synthetic: 120 JPEGs of the
 flower set's common sizes (500x375 / 500x333, quality 90) in five class directories.
 
-    python tools/bench_single.py [--epochs 40]
+    python tools/bench_single.py [--epochs 600]
 """
 import argparse
 import os
@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--epochs", type=int, default=100)
+    ap.add_argument("--epochs", type=int, default=600)
     args = ap.parse_args()
     from bench_input import make_jpegs
 
