@@ -184,8 +184,9 @@ _workspaces = {}
 
 
 def workspace(device, nbytes: int) -> torch.Tensor:
-    """Grow-only per-device scratch buffer (fp32 elements)."""
-    key = torch.device(device).index
+    """Grow-only scratch buffer (fp32 elements), one per device and stream: launches on different streams may
+    overlap, launches on one stream use theirs one after the other."""
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
     w = _workspaces.get(key)
     need = (nbytes + 3) // 4
     if w is None or w.numel() < need:
