@@ -30,6 +30,10 @@ struct WgradArgs {
   int splits;
   // decomposition of one k-tile step (BKP pixels) into (images, rows, cols)
   int step_b, step_y, step_x;
+  // floats between the slabs of consecutive splits: Cout * K, plus K when the launch also sums the columns of X
+  // (``colsum``: sum_m X[pixel(m) + tap][ci], written behind the split's [Cout][K] block)
+  long long slab_stride;
+  int colsum;
 };
 
 #define MAX_TAPS 64
@@ -52,7 +56,10 @@ __device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
 #define WGRAD_MFMA_FIRST 0
 #endif
 
-template <int BMW, int BNW, int BKP>
+// ONES: the launch also produces the column sums of its X operand over the pixels, sum_m X[m][n] -- one more MFMA
+// per fragment column with an all-ones row operand held in registers, in the waves of the first row of tiles.  The
+// moments a folded batch-norm needs of a tensor (x^T x and x^T 1) then come from one pass over it.
+template <int BMW, int BNW, int BKP, bool ONES = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int RBA = BMW * 2, RBB = BNW * 2;       // row bytes
   constexpr int CPRA = RBA / 16, CPRB = RBB / 16;   // 16-byte chunks per row
@@ -169,6 +176,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+  f32x16 ones_acc[ONES ? NT : 1];
+  const bool sum_cols = ONES && tile_m == 0 && wr == 0;   // wave-uniform
+  bf16x8 ones_frag;
+  if (ONES) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) ones_acc[nt][j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones_frag[j] = (bf16)1.0f;
+  }
 
   // NST LDS stages: while k-tile kt is multiplied, the tiles up to kt+NST-1 are in flight (counted vmcnt,
   // raw barrier: __syncthreads() would drain every outstanding LDS-DMA load).  Fragments of k-step ks+1 are
@@ -206,6 +224,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
             __builtin_bit_cast(bf16x8, af[src][mt]), __builtin_bit_cast(bf16x8, bfr[src][nt]), acc[mt][nt], 0, 0, 0);
+    if (ONES && sum_cols) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        ones_acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_frag, __builtin_bit_cast(bf16x8, bfr[src][nt]),
+                                                              ones_acc[nt], 0, 0, 0);
+    }
   };
 
   if (kt_begin < kt_end) {
@@ -259,8 +283,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   }
 
   // ---- store the fp32 partial tile ----
-  float* slab = p.slab + (size_t)split * p.Cout * p.K;
+  float* slab = p.slab + (size_t)split * p.slab_stride;
   const int colq = lane & 31, khalf = lane >> 5;
+  if (ONES && sum_cols && khalf == 0) {
+    // every row of the ones product holds the column sums; row 0 is element 0 of the lanes 0..31
+    float* cs = slab + (size_t)p.Cout * p.K;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * WN + nt * 32 + colq;
+      if (n < p.K) cs[n] = ones_acc[nt][0];
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -316,7 +349,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
-template <int BMW, int BNW, int BKP>
+template <int BMW, int BNW, int BKP, bool ONES = false>
 static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t stream) {
   size_t lds = MAX_TAPS * 4 + (BKP == 32 ? 3 : 2) * (size_t)BKP * (BMW * 2 + BNW * 2);
   unsigned mt = (a.Cout + BMW - 1) / BMW, nt = (a.K + BNW - 1) / BNW;
@@ -326,11 +359,11 @@ static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t stream) {
   (void)hipGetDevice(&dev);
   dev = (dev >= 0 && dev < 64) ? dev : 0;
   if (!attr_set[dev] && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, BKP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, BKP, ONES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set[dev] = true;
   }
   unsigned split_groups = (splits + 7) / 8;
-  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, BKP>), dim3(mt * nt * split_groups * 8), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, BKP, ONES>), dim3(mt * nt * split_groups * 8), dim3(256), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -345,6 +378,19 @@ extern "C" int dtfa_conv_wgrad(WgradArgs* a, int bmw, int bnw, int bkp, int spli
   int rem = bkp % opix;
   a->step_y = rem / a->OW;
   a->step_x = rem % a->OW;
+  a->slab_stride = (long long)a->Cout * a->K + (a->colsum ? a->K : 0);
+  if (a->colsum) {
+    // column sums ride on the tiles used for x^T x of 64 .. 512 channels
+#define CASE1(A_, B_, C_) \
+  if (bmw == A_ && bnw == B_ && bkp == C_) return launch_wgrad<A_, B_, C_, true>(*a, splits, stream);
+    CASE1(256, 128, 32)
+    CASE1(128, 128, 32)
+    CASE1(128, 128, 64)
+    CASE1(64, 64, 32)
+    CASE1(64, 64, 64)
+#undef CASE1
+    return -4;
+  }
 #define CASE(A_, B_, C_) \
   if (bmw == A_ && bnw == B_ && bkp == C_) return launch_wgrad<A_, B_, C_>(*a, splits, stream);
   CASE(256, 128, 32)

@@ -682,11 +682,22 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Option
     return dx
 
 
+_WGRAD_COLSUM_TILES = {(256, 128, 32), (128, 128, 32), (128, 128, 64), (64, 64, 32), (64, 64, 64)}
+
+
+def wgrad_colsum_ok(plan: ConvPlan, M: int) -> bool:
+    """The weight-gradient launch of ``plan`` over ``M`` pixels can also sum the columns of its X operand."""
+    return plan.T == 1 and pick_wgrad_tile(M, plan.cout, plan.K, plan.cin)[:3] in _WGRAD_COLSUM_TILES
+
+
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[torch.Tensor] = None,
-               accumulate: bool = False) -> torch.Tensor:
+               accumulate: bool = False, colsum: bool = False):
     """Weight gradient [Cout,KH,KW,Cin].  ``out`` may be an fp32 or bf16 buffer
     of the right size (written, or added to when ``accumulate``); by default a
-    new fp32 tensor is returned."""
+    new fp32 tensor is returned.
+
+    ``colsum`` (1x1 layers, no ``out``): returns ``(dW, s)`` with ``s[ci] = sum over pixels of x[..., ci]`` (fp32),
+    computed by the same launch from the X fragments it already holds (see ``wgrad_colsum_ok``)."""
     hipk.require(x, torch.bfloat16, "x")
     hipk.require(dy, torch.bfloat16, "dy")
     B = x.shape[0]
@@ -697,6 +708,12 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
         raise ValueError("too many pixels for 32-bit indices")
     bmw, bnw, bkp, splits = pick_wgrad_tile(M, plan.cout, plan.K, plan.cin)
     n = plan.cout * plan.K
+    if colsum:
+        if out is not None or not wgrad_colsum_ok(plan, M):
+            raise ValueError("column sums ride on 1x1 weight-gradient launches with one of the tiles built for them")
+        both = torch.empty(n + plan.K, dtype=torch.float32, device=x.device)
+        out = both[:n].view(plan.cout, plan.kh, plan.kw, plan.cin)
+        accumulate = False
     if out is None:
         out = torch.empty((plan.cout, plan.kh, plan.kw, plan.cin), dtype=torch.float32, device=x.device)
         accumulate = False
@@ -706,7 +723,8 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
         raise ValueError("accumulation needs an fp32 gradient buffer")
     # an unsplit reduction (few pixels: dense layers at small batch) writes the fp32 gradient in place
     direct = splits == 1 and out.dtype == torch.float32 and not accumulate
-    slab = out if direct else hipk.workspace(x.device, splits * n * 4)
+    per_split = n + (plan.K if colsum else 0)
+    slab = (both if colsum else out) if direct else hipk.workspace(x.device, splits * per_split * 4)
     L = hipk.lib()
     a = hipk.WgradArgs()
     a.x, a.dy, a.slab = x.data_ptr(), dy.data_ptr(), slab.data_ptr()
@@ -717,7 +735,13 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
     a.isy, a.isx = plan.sy, plan.sx
     a.T, a.M, a.K = plan.T, M, plan.K
     a.cin_magic = plan.cin_magic
+    a.colsum = 1 if colsum else 0
     hipk.check(L.dtfa_conv_wgrad(C.byref(a), bmw, bnw, bkp, splits, hipk.stream()), "conv_wgrad")
+    if colsum:
+        if not direct:
+            hipk.check(L.dtfa_wgrad_reduce(slab.data_ptr(), splits, per_split, both.data_ptr(), None, 0, hipk.stream()),
+                       "wgrad_reduce")
+        return out, both[n:]
     if direct:
         return out
     f32 = out.data_ptr() if out.dtype == torch.float32 else None

@@ -487,9 +487,13 @@ def _fold_stats(x, weight, gamma, beta, run_mean, run_var, eps, momentum):
     N, C = weight.shape[0], x.shape[-1]
     M = x.numel() // C
     gplan = cv.get_plan(x.shape[1], x.shape[2], C, C, 1, 1, 1, 1, (0, 0, 0, 0), x.device)
-    S = torch.empty((C, C), dtype=F32, device=x.device)
-    cv.conv_wgrad(x, x, gplan, out=S)
-    s = _col_sums(x)
+    if cv.wgrad_colsum_ok(gplan, M):
+        S, s = cv.conv_wgrad(x, x, gplan, colsum=True)   # x^T x and x^T 1 from one pass over x
+        S = S.view(C, C)
+    else:
+        S = torch.empty((C, C), dtype=F32, device=x.device)
+        cv.conv_wgrad(x, x, gplan, out=S)
+        s = _col_sums(x)
     W32 = weight.reshape(N, C).float()
     T = W32 @ S
     mean, invstd, scale, shift = K.fold_forward(weight, T, s, gamma, beta, run_mean, run_var, M, eps, momentum)

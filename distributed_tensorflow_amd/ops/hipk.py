@@ -55,6 +55,7 @@ class WgradArgs(C.Structure):
         ("T", c_int), ("M", c_int), ("K", c_int),
         ("cin_magic", C.c_uint), ("ktiles_per_split", c_int), ("splits", c_int),
         ("step_b", c_int), ("step_y", c_int), ("step_x", c_int),
+        ("slab_stride", c_ll), ("colsum", c_int),
     ]
 
 

@@ -276,3 +276,22 @@ def test_dense_skinny_matches_fp32_reference(M, N, K, relu, bias):
         want = torch.relu(want)
     assert got.shape == (M, N) and got.dtype == torch.bfloat16
     torch.testing.assert_close(got.float(), want, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("B,hw,C,N", [(64, 28, 64, 64), (32, 14, 128, 128), (16, 14, 256, 256), (8, 7, 512, 512), (3, 5, 64, 64),
+                                      (16, 14, 128, 512)])
+def test_wgrad_column_sums_ride_along(B, hw, C, N):
+    """``colsum``: x^T 1 from the launch that computes dy^T x, equal to the separately computed gradient and the
+    fp32 column sums of x."""
+    g = torch.Generator().manual_seed(C + N)
+    x = torch.randn(B, hw, hw, C, generator=g).bfloat16().cuda()
+    dy = x if N == C else torch.randn(B, hw, hw, N, generator=g).bfloat16().cuda()
+    plan = cv.get_plan(hw, hw, C, N, 1, 1, 1, 1, (0, 0, 0, 0), "cuda")
+    M = B * hw * hw
+    if not cv.wgrad_colsum_ok(plan, M):
+        pytest.skip("tile of this shape has no column-sum build")
+    want = cv.conv_wgrad(x, dy, plan)
+    got, s = cv.conv_wgrad(x, dy, plan, colsum=True)
+    assert torch.equal(got, want)
+    ref = x.double().reshape(-1, C).sum(0)
+    torch.testing.assert_close(s.double(), ref, rtol=1e-4, atol=1e-2)

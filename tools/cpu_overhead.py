@@ -21,7 +21,7 @@ def main():
     model = build_model(name, num_classes=5, device=dev)
     model.train()
     engine = DataParallelEngine(model, mode="sync_dp", optimizer="momentum", lr=0.01, opt_kwargs={"momentum": 0.9})
-    x = torch.zeros(batch, size, size, 8, device=dev, dtype=torch.bfloat16)
+    x = torch.zeros(batch, size, size, getattr(model, "input_channels", 8), device=dev, dtype=torch.bfloat16)
     x[..., :3].uniform_(-1, 1)
     y = torch.randint(0, 5, (batch,), device=dev, dtype=torch.int32)
 
