@@ -591,16 +591,21 @@ class BnBackwardTap:
             raise ValueError("bad relu_mode")
 
 
+_TAP_PHASES = os.environ.get("DTFA_TAP_PHASES", "1") == "1"
+
+
 def dgrad_can_tap(plan: ConvPlan) -> bool:
-    """One launch writes every input pixel (unit stride): its epilogue sees the complete gradient."""
-    return len(plan.phases) == 1 and not plan.dgrad_needs_zero
+    """Every input pixel is written by exactly one data-gradient launch (one launch at unit stride, one per
+    output-stride phase otherwise), whose epilogue therefore sees the complete gradient of its pixels: the launches
+    can emit the batch-norm backward partial sums of the layer below (their rows simply add up)."""
+    return (len(plan.phases) == 1 or (_TAP_PHASES and len(plan.phases) > 1)) and not plan.dgrad_needs_zero
 
 
 def dgrad_coarse_addend_ok(plan: ConvPlan, stride) -> bool:
     """The data gradient of ``plan`` can add a gradient that lives on the grid ``[::sy, ::sx]`` of its output: one launch
     over a dense output, strides powers of two up to 16."""
     sy, sx = stride
-    return (dgrad_can_tap(plan) and plan.sy == 1 and plan.sx == 1 and 1 <= sy <= 16 and 1 <= sx <= 16
+    return (dgrad_can_tap(plan) and len(plan.phases) == 1 and plan.sy == 1 and plan.sx == 1 and 1 <= sy <= 16 and 1 <= sx <= 16
             and sy & (sy - 1) == 0 and sx & (sx - 1) == 0)
 
 
@@ -657,12 +662,13 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Option
         raise ValueError("addend_mask without addend")
     if bn_tap is not None:
         if not dgrad_can_tap(plan):
-            raise ValueError("batch-norm partials need a single-launch data gradient")
+            raise ValueError("batch-norm partials need a data gradient that writes every pixel")
         bn_tap.validate((B, plan.ih, plan.iw, plan.cin), plan.cin)
     if plan.dgrad_needs_zero:
         dx = torch.zeros((B, plan.ih, plan.iw, plan.cin), dtype=torch.bfloat16, device=dy.device)
     else:
         dx = torch.empty((B, plan.ih, plan.iw, plan.cin), dtype=torch.bfloat16, device=dy.device)
+    parts = []
     for ph in plan.phases:
         if wd is None:
             wp = torch.empty((plan.cin, ph.T * plan.cout), dtype=torch.bfloat16, device=dy.device)
@@ -676,9 +682,10 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Option
                              x2=x2, dbias=dbias,
                              addend_shift=(addend_stride[0].bit_length() - 1, addend_stride[1].bit_length() - 1)
                              if addend is not None else (0, 0))
-        if bn_tap is not None:
-            bn_tap.partials = part
-            bn_tap.gated = bn_tap.gate_store
+        parts.append(part)
+    if bn_tap is not None:
+        bn_tap.partials = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+        bn_tap.gated = bn_tap.gate_store
     return dx
 
 

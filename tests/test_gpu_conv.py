@@ -202,7 +202,8 @@ def test_dgrad_coarse_grid_addend(case, stride, gated):
 
 @pytest.mark.parametrize("relu_mode", [0, 2, 3])
 @pytest.mark.parametrize("case", [(2, 14, 14, 64, 32, 1, 1, 1, 1, "VALID"), (3, 9, 11, 40, 72, 3, 3, 1, 1, "SAME"),
-                                  (2, 12, 12, 64, 64, 3, 3, 1, 1, "SAME")])
+                                  (2, 12, 12, 64, 64, 3, 3, 1, 1, "SAME"), (2, 12, 12, 64, 64, 3, 3, 2, 2, "SAME"),
+                                  (3, 9, 11, 40, 72, 3, 3, 2, 2, "SAME"), (2, 14, 14, 128, 128, 3, 3, 2, 2, (1, 1, 1, 1))])
 def test_dgrad_emits_bn_backward_partials(case, relu_mode):
     """A data-gradient launch can emit (sum g, sum g*xhat) of the batch-norm layer below it; the sums equal
     those of the gradient tensor it wrote."""
