@@ -395,7 +395,9 @@ def dense_skinny_ok(rows: int, n_in: int, n_out: int) -> bool:
 
 
 def dense_skinny(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
-    """``act(x [M, K] @ w [N, K]^T + bias)`` for few rows: the reduction, not the output, is spread over the waves."""
+    """``act(x [M, K] @ w [N, K]^T + bias)`` for few rows: the reduction, not the output, is spread over the waves.
+    (The two dense layers of the reference's head at its batch of 32,
+    recognition_flower/single/flower_train.py:72-84, and every dense layer when serving single images.)"""
     hipk.require(x, torch.bfloat16, "x")
     hipk.require(w, torch.bfloat16, "w")
     M, Kd = x.shape

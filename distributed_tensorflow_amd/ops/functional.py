@@ -267,7 +267,8 @@ def run_branches(x: torch.Tensor, jobs) -> None:
 # ----------------------------------------------------------------------------
 # batch statistics of small forward-only layers: fp64 accumulators instead of partial rows + a reduction launch
 # ----------------------------------------------------------------------------
-# A frozen trunk evaluated with batch statistics at a small batch (the Inception-v3 trunk at batch 32) is ~94 layers
+# A frozen trunk evaluated with batch statistics at a small batch (the reference's configuration: Inception-v3 built
+# with is_training=True and fed 32 images, recognition_flower/single/flower_train.py:111,177-187) is ~94 layers
 # of 10 .. 20 us convolutions; reducing each layer's partial statistics rows in a kernel of its own was a tenth of
 # the step.  Inside a ``stat_scope`` such layers (at most STAT_ACC_MAX_ROWS output pixels, nothing requiring grad)
 # let the convolution add its column sums to a slice of one zeroed fp64 buffer and the normalisation kernel derive
