@@ -14,7 +14,8 @@
 
 __global__ void bn_relu_maxpool_fwd_kernel(const bf16* __restrict__ y, const float* __restrict__ scale,
                                            const float* __restrict__ shift, bf16* __restrict__ out,
-                                           unsigned char* __restrict__ idx, PoolArgs p, int relu, size_t nvec) {
+                                           unsigned char* __restrict__ idx, bf16* __restrict__ ywin, PoolArgs p,
+                                           int relu, size_t nvec) {
   const int cvec = p.C >> 3;
   // (the launcher guarantees nvec < 2^31: 32-bit index arithmetic)
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)nvec; i += gridDim.x * blockDim.x) {
@@ -30,10 +31,12 @@ __global__ void bn_relu_maxpool_fwd_kernel(const bf16* __restrict__ y, const flo
     const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
     float best[8];
     unsigned char bi[8];
+    bf16 braw[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       best[j] = -INFINITY;
       bi[j] = 255;
+      braw[j] = (bf16)0.f;
     }
     for (int ky = 0; ky < p.kh; ++ky) {
       const int iy = oy * p.sy + ky - p.pt;
@@ -53,6 +56,7 @@ __global__ void bn_relu_maxpool_fwd_kernel(const bf16* __restrict__ y, const flo
           if (f > best[j] || bi[j] == 255) {
             best[j] = f;
             bi[j] = tap;
+            braw[j] = v[j];
           }
         }
       }
@@ -66,6 +70,12 @@ __global__ void bn_relu_maxpool_fwd_kernel(const bf16* __restrict__ y, const flo
       packed.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((unsigned)bi[3] << 24);
       packed.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | ((unsigned)bi[7] << 24);
       *(uint2*)(idx + (size_t)i * 8) = packed;
+    }
+    if (ywin) {
+      bf16x8 w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = braw[j];
+      *(bf16x8*)(ywin + (size_t)i * 8) = w;
     }
   }
 }
@@ -85,7 +95,7 @@ typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_packed_kernel(
     const bf16* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
-    bf16* __restrict__ out, unsigned char* __restrict__ idx, PoolArgs p, unsigned nvec) {
+    bf16* __restrict__ out, unsigned char* __restrict__ idx, bf16* __restrict__ ywin, PoolArgs p, unsigned nvec) {
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= nvec) return;
   const unsigned cvec = (unsigned)p.C >> 3;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_packed_kernel(
           unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2p, best[j]), __builtin_bit_cast(i16x2p, w)));
     }
   // winning taps, two 16-bit fields per register
-  unsigned win[4] = {0u, 0u, 0u, 0u};
+  unsigned win[4] = {0u, 0u, 0u, 0u}, wraw[4] = {0u, 0u, 0u, 0u};   // (wraw: the winners' un-normalised values)
 #pragma unroll
   for (int tp = NT - 1; tp >= 0; --tp)
 #pragma unroll
@@ -142,6 +152,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_packed_kernel(
       const unsigned lo = (x & 0xffffu) == 0 ? 0xffffu : 0u, hi = (x >> 16) == 0 ? 0xffff0000u : 0u;
       const unsigned m = lo | hi;
       win[j] = (win[j] & ~m) | ((unsigned)tp * 0x00010001u & m);
+      wraw[j] = (wraw[j] & ~m) | (raw[tp][j] & m);
     }
   u32x4p o = {best[0], best[1], best[2], best[3]};
   *(u32x4p*)(out + (size_t)i * 8) = o;
@@ -150,6 +161,10 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_packed_kernel(
     packed.x = (win[0] & 0xffu) | ((win[0] >> 8) & 0xff00u) | ((win[1] & 0xffu) << 16) | ((win[1] >> 16) << 24);
     packed.y = (win[2] & 0xffu) | ((win[2] >> 8) & 0xff00u) | ((win[3] & 0xffu) << 16) | ((win[3] >> 16) << 24);
     *(uint2*)(idx + (size_t)i * 8) = packed;
+  }
+  if (ywin) {
+    u32x4p w = {wraw[0], wraw[1], wraw[2], wraw[3]};
+    *(u32x4p*)(ywin + (size_t)i * 8) = w;
   }
 }
 
@@ -282,6 +297,82 @@ __global__ void bn_pool_bwd_partials_kernel(const bf16* __restrict__ dp, const u
     for (int j = 0; j < 8; ++j) {
       dst[j] = s1[j];
       dst[p.C + j] = s2[j];
+    }
+  }
+}
+
+// The same sums when the forward pass kept each window's winning convolution output (``ywin``, pooled shape): two
+// contiguous streams, the pooled gradient and the winners' values, instead of a 2-byte gather per element into
+// the full-resolution tensor (which touched most of its lines: 3.3 GB for the ResNet stem at batch 2048).
+__global__ void bn_pool_bwd_partials_ywin_kernel(const bf16* __restrict__ dp, const bf16* __restrict__ ywin,
+                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                 float* __restrict__ out, int C, long long M, int relu, int TX,
+                                                 long long rows_per_block) {
+  extern __shared__ float red[];  // [TY][TX][16]
+  const int TY = blockDim.x / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cg = blockIdx.x * TX + tx;
+  const int cvec = C >> 3;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  if (cg < cvec) {
+    float mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mu[j] = mean[cg * 8 + j];
+      is[j] = invstd[cg * 8 + j];
+      sc[j] = scale[cg * 8 + j];
+      sh[j] = shift[cg * 8 + j];
+    }
+    long long r0l = (long long)blockIdx.y * rows_per_block, r1l = r0l + rows_per_block;
+    if (r1l > M) r1l = M;
+    constexpr int U = 4;
+    for (long long r = r0l + ty; r < r1l; r += (long long)TY * U) {
+      bf16x8 g[U], yw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long rr = r + (long long)u * TY;
+        const size_t o = (size_t)(rr < r1l ? rr : r) * C + cg * 8;
+        g[u] = __builtin_nontemporal_load((const bf16x8*)(dp + o));
+        yw[u] = __builtin_nontemporal_load((const bf16x8*)(ywin + o));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (r + (long long)u * TY >= r1l) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float yf = (float)yw[u][j];
+          float gj = (float)g[u][j];
+          if (relu && !(yf * sc[j] + sh[j] > 0.f)) gj = 0.f;
+          s1[j] += gj;
+          s2[j] += gj * ((yf - mu[j]) * is[j]);
+        }
+      }
+    }
+  }
+  float* mine = red + ((size_t)ty * TX + tx) * 16;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mine[j] = s1[j];
+    mine[8 + j] = s2[j];
+  }
+  __syncthreads();
+  if (ty == 0 && cg < cvec) {
+    for (int t = 1; t < TY; ++t) {
+      const float* o = red + ((size_t)t * TX + tx) * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s1[j] += o[j];
+        s2[j] += o[8 + j];
+      }
+    }
+    float* dst = out + (size_t)blockIdx.y * 2 * C + (size_t)cg * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dst[j] = s1[j];
+      dst[C + j] = s2[j];
     }
   }
 }
@@ -455,21 +546,21 @@ static unsigned grid_1d(size_t nvec) {
 }
 
 extern "C" int dtfa_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, void* out, void* idx,
-                                        const PoolArgs* p, int relu, hipStream_t st) {
+                                        void* ywin, const PoolArgs* p, int relu, hipStream_t st) {
   if (!pool_args_ok(p)) return -1;
   size_t nvec = (size_t)p->B * p->OH * p->OW * p->C / 8;
   if (relu && p->kh == p->kw && (p->kh == 3 || p->kh == 2)) {
     const dim3 grid((unsigned)((nvec + 255) / 256));
     if (p->kh == 3)
       hipLaunchKernelGGL((bn_relu_maxpool_fwd_packed_kernel<3, 3>), grid, dim3(256), 0, st, (const bf16*)y, scale,
-                         shift, (bf16*)out, (unsigned char*)idx, *p, (unsigned)nvec);
+                         shift, (bf16*)out, (unsigned char*)idx, (bf16*)ywin, *p, (unsigned)nvec);
     else
       hipLaunchKernelGGL((bn_relu_maxpool_fwd_packed_kernel<2, 2>), grid, dim3(256), 0, st, (const bf16*)y, scale,
-                         shift, (bf16*)out, (unsigned char*)idx, *p, (unsigned)nvec);
+                         shift, (bf16*)out, (unsigned char*)idx, (bf16*)ywin, *p, (unsigned)nvec);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid_1d(nvec)), dim3(256), 0, st, (const bf16*)y, scale, shift,
-                     (bf16*)out, (unsigned char*)idx, *p, relu, nvec);
+                     (bf16*)out, (unsigned char*)idx, (bf16*)ywin, *p, relu, nvec);
   return (int)hipGetLastError();
 }
 
@@ -494,14 +585,20 @@ extern "C" int dtfa_bn_pool_partials_rows(const PoolArgs* p) {
   return gy;
 }
 
-extern "C" int dtfa_bn_pool_bwd_partials(const void* dp, const void* idx, const void* y, const float* mean,
-                                         const float* invstd, const float* scale, const float* shift, float* out,
-                                         const PoolArgs* p, int relu, hipStream_t st) {
+extern "C" int dtfa_bn_pool_bwd_partials(const void* dp, const void* idx, const void* y, const void* ywin,
+                                         const float* mean, const float* invstd, const float* scale,
+                                         const float* shift, float* out, const PoolArgs* p, int relu, hipStream_t st) {
   if (!pool_args_ok(p)) return -1;
   int TX, gx, gy;
   long long rpb;
   if (p->kw > 16) return -1;
   partials_geometry((long long)p->B * p->OH * p->OW, p->C, &TX, &gx, &gy, &rpb);
+  if (ywin != nullptr) {
+    hipLaunchKernelGGL(bn_pool_bwd_partials_ywin_kernel, dim3(gx, gy), dim3(256), 256 * 16 * sizeof(float), st,
+                       (const bf16*)dp, (const bf16*)ywin, mean, invstd, scale, shift, out, p->C,
+                       (long long)p->B * p->OH * p->OW, relu, TX, rpb);
+    return (int)hipGetLastError();
+  }
   const unsigned kw_magic = 65536u / (unsigned)p->kw + 1u;
   hipLaunchKernelGGL(bn_pool_bwd_partials_kernel, dim3(gx, gy), dim3(256), 256 * 16 * sizeof(float), st,
                      (const bf16*)dp, (const unsigned char*)idx, (const bf16*)y, mean, invstd, scale, shift, out, *p,

@@ -681,6 +681,9 @@ def _expand_fold_ok(plan, x, residual, relu, training, links) -> bool:
 
 
 
+POOL_WINNERS = os.environ.get("DTFA_POOL_WINNERS", "1") == "1"
+
+
 class _ConvBnActPoolFn(Function):
     """conv -> batch-norm -> ReLU -> max-pool; the full-resolution activation is never stored."""
 
@@ -695,15 +698,20 @@ class _ConvBnActPoolFn(Function):
             scale, shift = K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
             mean = invstd = None
         k, stride, pads = pool
-        out, idx = K.bn_relu_maxpool_fwd(y, scale, shift, relu, k, stride, pads, want_index=need_grad)
+        ywin = None
+        if need_grad and training and POOL_WINNERS:
+            # the winners' values: a quarter of y's bytes (stride-2 pool) written once, read once by the backward sums
+            out, idx, ywin = K.bn_relu_maxpool_fwd(y, scale, shift, relu, k, stride, pads, want_winners=True)
+        else:
+            out, idx = K.bn_relu_maxpool_fwd(y, scale, shift, relu, k, stride, pads, want_index=need_grad)
         ctx.plan, ctx.relu, ctx.training, ctx.params, ctx.pool = plan, relu, training, params, pool
         if need_grad:
-            ctx.save_for_backward(x, weight, y, idx, gamma, mean, invstd, scale, shift)
+            ctx.save_for_backward(x, weight, y, idx, gamma, mean, invstd, scale, shift, ywin)
         return out
 
     @staticmethod
     def backward(ctx, dp):
-        x, weight, y, idx, gamma, mean, invstd, scale, shift = ctx.saved_tensors
+        x, weight, y, idx, gamma, mean, invstd, scale, shift, ywin = ctx.saved_tensors
         plan = ctx.plan
         wparam, gparam, bparam = ctx.params
         k, stride, pads = ctx.pool
@@ -718,7 +726,7 @@ class _ConvBnActPoolFn(Function):
                                          and getattr(gparam, "_grad_filled", False) == filled)))
         dy, dgamma, dbeta = K.bn_pool_backward(dp, idx, y, mean, invstd, gamma, scale, shift, ctx.relu, k, stride, pads,
                                                dgamma_out=g_mg if direct else None, dbeta_out=b_mg if direct else None,
-                                               accumulate=filled if direct else False)
+                                               accumulate=filled if direct else False, ywin=ywin)
         gx = gw = gg = gb = None
         if ctx.needs_input_grad[1]:
             gw = _deliver_wgrad(wparam if wparam is not None else weight, x, dy, plan)

@@ -115,10 +115,10 @@ class _Sigs:
                      c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_void]
     dtfa_relu_bwd = [c_void, c_void, c_void, c_ll, c_void]
     dtfa_add_bf16 = [c_void, c_void, c_void, c_ll, c_void]
-    dtfa_bn_relu_maxpool_fwd = [c_void, c_void, c_void, c_void, c_void, C.POINTER(PoolArgs), c_int, c_void]
+    dtfa_bn_relu_maxpool_fwd = [c_void, c_void, c_void, c_void, c_void, c_void, C.POINTER(PoolArgs), c_int, c_void]
     dtfa_bn_pool_partials_rows = [C.POINTER(PoolArgs)]
-    dtfa_bn_pool_bwd_partials = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, C.POINTER(PoolArgs),
-                                 c_int, c_void]
+    dtfa_bn_pool_bwd_partials = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void,
+                                 C.POINTER(PoolArgs), c_int, c_void]
     dtfa_bn_pool_bwd_apply = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void,
                               C.POINTER(PoolArgs), c_int, c_void]
     dtfa_maxpool_fwd = [c_void, c_void, c_void, C.POINTER(PoolArgs), c_void]

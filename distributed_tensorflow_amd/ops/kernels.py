@@ -401,9 +401,10 @@ def maxpool_bwd(dy, idx, x_shape, k, stride, pads):
     return dx
 
 
-def bn_relu_maxpool_fwd(y, scale, shift, relu: bool, k, stride, pads, want_index=True):
+def bn_relu_maxpool_fwd(y, scale, shift, relu: bool, k, stride, pads, want_index=True, want_winners=False):
     """``maxpool(act(y*scale + shift))`` without storing the full-resolution activation.
-    Returns (pooled, winning-tap bytes or None)."""
+    Returns (pooled, winning-tap bytes or None); with ``want_winners`` also the un-normalised value ``y`` of every
+    window's winner (pooled shape, bf16) -- what the batch-norm backward sums need of ``y``."""
     hipk.require(y, BF16, "y")
     Cc = y.shape[3]
     if scale.numel() != Cc or shift.numel() != Cc or scale.dtype != F32 or shift.dtype != F32:
@@ -412,17 +413,20 @@ def bn_relu_maxpool_fwd(y, scale, shift, relu: bool, k, stride, pads, want_index
     p = _pool_args(y.shape, k, stride, pads, oh, ow)
     out = torch.empty((y.shape[0], oh, ow, Cc), dtype=BF16, device=y.device)
     idx = torch.empty(out.shape, dtype=torch.uint8, device=y.device) if want_index else None
+    ywin = torch.empty_like(out) if want_winners else None
     hipk.check(hipk.lib().dtfa_bn_relu_maxpool_fwd(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
-                                                   hipk.ptr(idx), C.byref(p), 1 if relu else 0, hipk.stream()),
+                                                   hipk.ptr(idx), hipk.ptr(ywin), C.byref(p), 1 if relu else 0,
+                                                   hipk.stream()),
                "bn_relu_maxpool_fwd")
-    return out, idx
+    return (out, idx, ywin) if want_winners else (out, idx)
 
 
 def bn_pool_backward(dp, idx, y, mean, invstd, gamma, scale, shift, relu: bool, k, stride, pads,
-                     dgamma_out=None, dbeta_out=None, accumulate=False):
+                     dgamma_out=None, dbeta_out=None, accumulate=False, ywin=None):
     """Backward of ``maxpool(act(bn(y)))`` given the pooled gradient ``dp`` and the winning-tap bytes:
     returns (dy, dgamma, dbeta).  The full-resolution gradient of the pool is gathered on the fly in both
-    passes and never stored."""
+    passes and never stored.  ``ywin`` (the winners' values kept by the forward pass) spares the first pass its
+    gather into ``y``."""
     hipk.require(dp, BF16, "dp")
     hipk.require(y, BF16, "y")
     hipk.require(idx, torch.uint8, "idx")
@@ -438,7 +442,11 @@ def bn_pool_backward(dp, idx, y, mean, invstd, gamma, scale, shift, relu: bool, 
     M = y.numel() // Cc
     rows = L.dtfa_bn_pool_partials_rows(C.byref(p))
     part = torch.empty((rows, 2, Cc), dtype=F32, device=y.device)
-    hipk.check(L.dtfa_bn_pool_bwd_partials(dp.data_ptr(), idx.data_ptr(), y.data_ptr(), mean.data_ptr(),
+    if ywin is not None:
+        hipk.require(ywin, BF16, "ywin")
+        if ywin.shape != dp.shape:
+            raise ValueError("bn_pool_backward: winners' values must have the pooled shape")
+    hipk.check(L.dtfa_bn_pool_bwd_partials(dp.data_ptr(), idx.data_ptr(), y.data_ptr(), hipk.ptr(ywin), mean.data_ptr(),
                                            invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), part.data_ptr(),
                                            C.byref(p), 1 if relu else 0, hipk.stream()), "bn_pool_bwd_partials")
     part = reduce_partials(part)

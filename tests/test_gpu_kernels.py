@@ -275,6 +275,17 @@ def test_bn_relu_maxpool_fused_matches_unfused(shape, k, stride, pads, relu):
     torch.testing.assert_close(dg, dg_ref, rtol=2e-2, atol=2e-2 * dg_ref.abs().max().item())
     torch.testing.assert_close(db, db_ref, rtol=2e-2, atol=2e-2 * db_ref.abs().max().item())
     assert (dy.float() - dy_ref.float()).abs().max().item() <= 3e-2 * dy_ref.float().abs().max().item()
+    # the winners' values kept by the forward pass: the pooled output is their image under the affine map + ReLU,
+    # and the backward sums read them instead of gathering from y -- same results, bit for bit
+    p_w, idx_w, ywin = K.bn_relu_maxpool_fwd(y, sc, sh, relu, k, stride, pads, want_winners=True)
+    assert torch.equal(p_w, p_fused) and torch.equal(idx_w, idx)
+    zw = ywin.float() * sc + sh
+    zw = (torch.relu(zw) if relu else zw).bfloat16()
+    assert torch.equal(zw, p_fused)
+    dy_w, dg_w, db_w = K.bn_pool_backward(dp, idx, y, mean, invstd, gamma, sc, sh, relu, k, stride, pads, ywin=ywin)
+    assert torch.equal(dy_w, dy)
+    torch.testing.assert_close(dg_w, dg, rtol=1e-5, atol=1e-5 * dg.abs().max().item())
+    torch.testing.assert_close(db_w, db, rtol=1e-5, atol=1e-5 * db.abs().max().item())
 
 
 @pytest.mark.parametrize("shape,relu,sliced", [((32, 17, 17, 192), True, True), ((32, 8, 8, 448), True, False),
