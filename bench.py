@@ -140,6 +140,9 @@ def main():
                     help="second model measured after the headline one and reported under \"also\" ('' = none)")
     ap.add_argument("--also_modes", default="sharded_ps,async_ssp",
                     help="distribution modes the headline model is measured in as well, reported under \"also\" ('' = none)")
+    ap.add_argument("--also_timeout", type=int, default=240,
+                    help="seconds the secondary (\"also\") runs may take before the headline result is reported "
+                         "without them (0 = no limit)")
     ap.add_argument("--hip_graph", type=int, default=-1,
                     help="1: record the whole step (fwd, bwd, collectives, optimizer) in a HIP graph and replay it; "
                          "default: on for inception_v3_head (hundreds of short kernels per step), off otherwise")
@@ -165,27 +168,10 @@ def main():
     import gc
 
     also = {}
-    if args.also and args.also != args.model:
-        # the second model of the headline metric (flower CNN), same K / W, measured after the headline run
-        gc.collect()
-        torch.cuda.empty_cache()
-        try:
-            r = run_config(args, args.also, DEFAULT_BATCH[args.also], device, rank, world)
-            also = {args.also: {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "final_loss")}}
-        except Exception as e:  # noqa: BLE001 -- the headline number stands on its own
-            also = {args.also: {"error": "%s: %s" % (type(e).__name__, e)}}
-    # the headline model in the other two distribution modes (sharded parameter ownership: reduce-scatter +
-    # all-gather; staleness-bounded asynchronous updates), same batch, same K / W
-    for other in [m for m in args.also_modes.split(",") if m and m != args.mode and not args.hip_graph]:
-        gc.collect()
-        torch.cuda.empty_cache()
-        key = "%s/%s" % (args.model, other)
-        try:
-            r = run_config(args, args.model, head["per_gpu_batch"], device, rank, world, mode=other)
-            also[key] = {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "final_loss")}
-        except Exception as e:  # noqa: BLE001
-            also[key] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if rank == 0:
+
+    def report():
+        if rank != 0:
+            return
         print(json.dumps({
             "metric": "train images/sec (whole node)",
             "value": head["value"],
@@ -210,6 +196,44 @@ def main():
             "comm": head["comm"],
             "also": also,
         }), flush=True)
+
+    # The headline number is measured; the secondary runs below must not be able to lose it.  If one of them
+    # hangs (a rank that failed inside a collective leaves its peers waiting), the watchdog reports the headline
+    # with whatever secondary results exist and ends the process.
+    import threading
+
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(args.also_timeout):
+            also["error"] = "secondary runs exceeded %d s and were abandoned" % args.also_timeout
+            report()
+            os._exit(0)
+
+    if args.also_timeout > 0:
+        threading.Thread(target=watchdog, daemon=True).start()
+    if args.also and args.also != args.model:
+        # the second model of the headline metric (flower CNN), same K / W, measured after the headline run
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            r = run_config(args, args.also, DEFAULT_BATCH[args.also], device, rank, world)
+            also[args.also] = {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "final_loss")}
+        except Exception as e:  # noqa: BLE001 -- the headline number stands on its own
+            also[args.also] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # the headline model in the other two distribution modes (sharded parameter ownership: reduce-scatter +
+    # all-gather; staleness-bounded asynchronous updates), same batch, same K / W
+    for other in [m for m in args.also_modes.split(",") if m and m != args.mode and not args.hip_graph]:
+        gc.collect()
+        torch.cuda.empty_cache()
+        key = "%s/%s" % (args.model, other)
+        try:
+            r = run_config(args, args.model, head["per_gpu_batch"], device, rank, world, mode=other)
+            also[key] = {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "final_loss")}
+        except Exception as e:  # noqa: BLE001
+            also[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    done.set()
+    report()
     if dist.is_initialized():
         dist.destroy_process_group()
 
