@@ -144,6 +144,7 @@ class _Sigs:
     dtfa_p2p_handle = [c_void, C.c_char_p]
     dtfa_p2p_connect = [c_void, C.c_char_p]
     dtfa_p2p_allreduce = [c_void, c_void, c_void, c_ll, c_int, c_float, c_void]
+    dtfa_p2p_allreduce2 = [c_void, c_void, c_void, c_ll, c_int, c_float, c_void]
     dtfa_p2p_status = [c_void]
 
 

@@ -30,24 +30,35 @@ def main():
         dist.barrier()
         os._exit(0)
     it = 0
+    # one-shot and two-shot calls share the mailbox, its sequence numbers and its two parities: interleave them.
+    # The two-shot form must also cope with sizes that do not divide into ``world`` slices (4, 4096 + 8 elements).
     for dtype in (torch.float32, torch.bfloat16):
         for n in (8, 1024, 4096 + 8, 65536, (1 << 20) // 4 if dtype == torch.float32 else (1 << 20) // 2):
-            for rep in range(5):
+            for rep in range(6):
                 it += 1
+                algo = ("one_shot", "two_shot", "auto")[rep % 3]
                 mine = data(rank, n, dtype, it).cuda()
+                ref = mine.clone()
                 want = sum(data(r, n, dtype, it).float() for r in range(world)) * 0.5
-                p2p.all_reduce_(mine, scale=0.5)
+                p2p.all_reduce_(mine, scale=0.5, algo=algo)
                 got = mine.float().cpu()
                 tol = 0 if dtype == torch.float32 else 2e-2
                 err = (got - want).abs().max().item()
-                assert err <= tol * max(1.0, want.abs().max().item()), (dtype, n, rep, err)
+                assert err <= tol * max(1.0, want.abs().max().item()), (dtype, n, rep, algo, err)
+                if algo == "two_shot":  # same bits as the one-shot form
+                    p2p.all_reduce_(ref, scale=0.5, algo="one_shot")
+                    assert torch.equal(ref, mine), (dtype, n, rep)
     p2p.check()
     # results are bit-identical across ranks
     t = data(rank, 4096, torch.float32, 999).cuda()
     p2p.all_reduce_(t)
-    both = [None, None]
+    both = [None] * world
     dist.all_gather_object(both, t.cpu())
-    assert torch.equal(both[0], both[1])
+    assert all(torch.equal(both[0], b) for b in both[1:])
+    t = data(rank, 40000, torch.bfloat16, 998).cuda()
+    p2p.all_reduce_(t, algo="two_shot")
+    dist.all_gather_object(both, t.cpu())
+    assert all(torch.equal(both[0], b) for b in both[1:])
     p2p.close()
     print("P2P_OK rank", rank, "calls", it, flush=True)
     dist.destroy_process_group()

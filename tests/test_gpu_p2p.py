@@ -1,5 +1,5 @@
-"""One-shot mailbox all-reduce: two rank processes on one GPU (IPC-mapped mailboxes, flag protocol,
-double buffering, rank-ordered summation, timeout when a peer never arrives)."""
+"""Mailbox all-reduce, one-shot and two-shot forms: two or three rank processes on one GPU (IPC-mapped
+mailboxes, flag protocol, double buffering, rank-ordered summation, timeout when a peer never arrives)."""
 import os
 import socket
 import subprocess
@@ -19,10 +19,10 @@ def _port():
     return str(p)
 
 
-def _launch(mode):
+def _launch(mode, world=2):
     port = _port()
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), "2", port, mode], stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, mode], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     try:
         for p in procs:
@@ -36,6 +36,13 @@ def _launch(mode):
 
 def test_p2p_allreduce_two_ranks_one_gpu():
     procs, outs = _launch("run")
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "P2P_OK" in o, o[-3000:]
+
+
+def test_p2p_allreduce_three_ranks_one_gpu():
+    """Three ranks: slices of unequal length in the two-shot form, ``auto`` picks it from 256 KiB."""
+    procs, outs = _launch("run", world=3)
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "P2P_OK" in o, o[-3000:]
 

@@ -6,8 +6,8 @@
                                    [--device cuda|cpu] [--iters 20] [--json out.json]
 
 For every message size (powers of four between ``--min_kb`` and ``--max_mb``) and every operation the engine uses --
-``all_reduce`` (sync_dp), ``reduce_scatter`` + ``all_gather`` (sharded_ps), and the one-shot xGMI mailbox all-reduce
-(``mailbox``, small buckets, GPUs only) -- it prints the time per call, the *algorithmic* bandwidth (message bytes /
+``all_reduce`` (sync_dp), ``reduce_scatter`` + ``all_gather`` (sharded_ps), and the xGMI mailbox all-reduce in its one-shot and two-shot forms
+(``mailbox`` / ``mailbox2``, small and medium buckets, GPUs only) -- it prints the time per call, the *algorithmic* bandwidth (message bytes /
 time: what a bucket sees) and the *bus* bandwidth (bytes each rank actually moves over its links / time: 2 (N-1)/N
 of the message for all-reduce, (N-1)/N for the other two), which is the number to hold against the ~153 GB/s of one
 xGMI link or the 7 links of a GPU.  A world of one (``DTFA_FORCE_COLLECTIVES``-style) measures the fixed launch cost
@@ -39,7 +39,7 @@ def sizes(min_kb: int, max_mb: int):
 def bus_factor(op: str, world: int) -> float:
     if world <= 1:
         return 1.0
-    return 2.0 * (world - 1) / world if op in ("all_reduce", "mailbox") else (world - 1) / world
+    return 2.0 * (world - 1) / world if op in ("all_reduce", "mailbox", "mailbox2") else (world - 1) / world
 
 
 def main():
@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--min_kb", type=int, default=64)
     ap.add_argument("--max_mb", type=int, default=256)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
-    ap.add_argument("--ops", default="all_reduce,reduce_scatter,all_gather,mailbox")
+    ap.add_argument("--ops", default="all_reduce,reduce_scatter,all_gather,mailbox,mailbox2")
     ap.add_argument("--device", default="auto")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -72,9 +72,9 @@ def main():
     esz = 4 if a.dtype == "fp32" else 2
     ops = [o for o in a.ops.split(",") if o]
     if not use_cuda:
-        ops = [o for o in ops if o != "mailbox"]  # hipIpc-mapped peer mailboxes exist on GPUs only
+        ops = [o for o in ops if not o.startswith("mailbox")]  # hipIpc-mapped peer mailboxes exist on GPUs only
     mailbox = None
-    if "mailbox" in ops:
+    if "mailbox" in ops or "mailbox2" in ops:
         from distributed_tensorflow_amd.parallel.p2p import P2PAllReduce
 
         mailbox = P2PAllReduce(int(a.mailbox_max_mb * (1 << 20)))
@@ -94,7 +94,7 @@ def main():
             n -= n % max(world * 64, 64)
             if n <= 0:
                 continue
-            if op == "mailbox" and (mailbox is None or n * esz > a.mailbox_max_mb * (1 << 20)):
+            if op.startswith("mailbox") and (mailbox is None or n * esz > a.mailbox_max_mb * (1 << 20)):
                 continue
             full = torch.ones(n, dtype=dtype, device=device)
             shard = torch.ones(n // world, dtype=dtype, device=device)
@@ -106,12 +106,12 @@ def main():
                     dist.reduce_scatter_tensor(shard, full)
                 elif op == "all_gather":
                     dist.all_gather_into_tensor(full, shard)
-                else:
-                    mailbox.all_reduce_(full)
+                else:  # mailbox: one-shot form, mailbox2: two-shot form (direct reduce-scatter + all-gather)
+                    mailbox.all_reduce_(full, algo="two_shot" if op == "mailbox2" else "one_shot")
 
             for _ in range(a.warmup):
                 call()
-                if op in ("all_reduce", "mailbox"):
+                if op in ("all_reduce", "mailbox", "mailbox2"):
                     full.fill_(1.0)  # keep the values finite over many in-place sums
             sync()
             t0 = time.perf_counter()
