@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: training throughput (images/sec, whole job) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--model resnet50|flower_cnn|inception_v3_head]
+    python bench.py --gpus N --steps K --warmup W [--model resnet50|flower_cnn|inception_v3_head|inception_v3_finetune]
                     [--mode sync_dp|sharded_ps|async_ssp] [--batch PER_GPU_BATCH]
 
 For N > 1 launch one rank per GPU with ``python -m torch.distributed.run`` (RANK /
@@ -33,8 +33,8 @@ from distributed_tensorflow_amd.parallel.engine import DataParallelEngine  # noq
 
 # per-GPU batches sized for 288 GB of HBM: ResNet-50 at 1024 holds ~40 GB of activations and runs ~13 % more
 # images/s than at 256 (fixed per-layer costs and tile-quantisation tails amortise)
-DEFAULT_BATCH = {"resnet50": 2048, "flower_cnn": 1024, "inception_v3_head": 256}
-IMAGE_SIZE = {"resnet50": 224, "flower_cnn": 224, "inception_v3_head": 299}
+DEFAULT_BATCH = {"resnet50": 2048, "flower_cnn": 1024, "inception_v3_head": 256, "inception_v3_finetune": 512}
+IMAGE_SIZE = {"resnet50": 224, "flower_cnn": 224, "inception_v3_head": 299, "inception_v3_finetune": 299}
 
 
 def run_config(args, model_name, batch, device, rank, world, mode=None):
@@ -45,7 +45,7 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
     kw = {"trunk_bn": args.trunk_bn} if model_name == "inception_v3_head" else {}
     model = build_model(model_name, num_classes=5, device=device, **kw)
     model.train()
-    if model_name == "inception_v3_head":
+    if model_name.startswith("inception_v3"):
         opt, lr, okw = "adam", 1e-3, {}
     else:
         # a fixed synthetic batch with random labels: a small constant rate keeps the loss finite at any world size

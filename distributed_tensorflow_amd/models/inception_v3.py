@@ -271,17 +271,28 @@ class InceptionV3Flower(nn.Module):
     features normalised differently from the ones the head was trained on).  Every conv + batch-norm +
     ReLU of the trunk is then one kernel, with the statistics folded into the convolution epilogue;
     ``PreLogits`` dropout still follows the train/eval mode.
+
+    ``train_trunk=True`` (model name ``inception_v3_finetune``) is the step the reference stops short of: every
+    convolution and batch-norm offset of the trunk is trained together with the head (the reference's
+    ``var_list=fc_vars`` dropped), so the step runs the data- and weight-gradient kernels of all 94 trunk layers,
+    the pooling backward passes and autograd's channel concatenation of the block branches.  The variables of
+    ``AuxLogits`` / ``Logits``, which no loss touches, stay frozen.
     """
 
-    def __init__(self, num_classes=5, head_dropout_rate=0.5, act_l2=0.0005, trunk_bn="batch"):
+    def __init__(self, num_classes=5, head_dropout_rate=0.5, act_l2=0.0005, trunk_bn="batch", train_trunk=False):
         super().__init__()
         if trunk_bn not in ("batch", "moving"):
             raise ValueError("trunk_bn must be 'batch' or 'moving'")
+        if train_trunk and trunk_bn != "batch":
+            raise ValueError("a trained trunk normalises with batch statistics (trunk_bn='batch')")
         self.trunk_bn = trunk_bn
+        self.train_trunk = bool(train_trunk)
         self.num_classes = num_classes
         self.trunk = InceptionV3()
+        unused = {id(p) for name in ("AuxLogits", "Logits_Conv2d_1c_1x1") if hasattr(self.trunk, name)
+                  for p in getattr(self.trunk, name).parameters()}
         for p in self.trunk.parameters():
-            p.requires_grad_(False)
+            p.requires_grad_(self.train_trunk and id(p) not in unused)
         self.head = FlowerHead(2048, num_classes, dropout_rate=head_dropout_rate, act_l2=act_l2)
 
     def train(self, mode: bool = True):
@@ -293,6 +304,8 @@ class InceptionV3Flower(nn.Module):
         return self
 
     def forward(self, x):
+        if self.train_trunk:
+            return self.head(self.trunk(x))
         with torch.no_grad():
             feats = self.trunk(x)
         return self.head(feats)

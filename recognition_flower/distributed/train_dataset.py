@@ -50,7 +50,7 @@ flags.DEFINE_integer("batch_size", 32, "Training batch size ")
 flags.DEFINE_float("learning_rate", 0.001, "Learning rate")
 # additions
 flags.DEFINE_string("mode", "async_ps", "async_ps | sync_dp | sharded_ps | async_ssp")
-flags.DEFINE_string("model", "auto", "inception_v3_head | flower_cnn | resnet50 | auto")
+flags.DEFINE_string("model", "auto", "inception_v3_head | inception_v3_finetune (the trunk is trained too) | flower_cnn | resnet50 | auto")
 flags.DEFINE_integer("image_size", 299, "Network input size.")
 flags.DEFINE_integer("staleness", -1, "Staleness bound (async_ps: -1 = unbounded; async_ssp: delay in steps).")
 flags.DEFINE_float("bucket_mb", 32.0, "Gradient bucket size for the collective modes.")
@@ -169,8 +169,12 @@ def run_worker(spec):
     torch.manual_seed(1234)  # identical initial values on every worker
     model_name = _model_name(device)
     n_classes = _num_classes()
-    kw = {"head_dropout_rate": FLAGS.head_dropout_rate, "trunk_bn": FLAGS.trunk_bn} if model_name == "inception_v3_head" else (
-        {"dropout_rate": FLAGS.head_dropout_rate} if model_name == "flower_cnn" else {})
+    if model_name == "inception_v3_head":
+        kw = {"head_dropout_rate": FLAGS.head_dropout_rate, "trunk_bn": FLAGS.trunk_bn}
+    elif model_name == "inception_v3_finetune":
+        kw = {"head_dropout_rate": FLAGS.head_dropout_rate}
+    else:
+        kw = {"dropout_rate": FLAGS.head_dropout_rate} if model_name == "flower_cnn" else {}
     model = build_model(model_name, num_classes=n_classes, device=device, **kw)
 
     opt_name = FLAGS.optimizer.lower()

@@ -44,7 +44,7 @@ flags.DEFINE_string("dataset_path", "../flower_photos_labeled", "Needs to provid
 flags.DEFINE_string("model_path", "", "Checkpoint prefix to restore before training (optional).")
 flags.DEFINE_string("summaries_dir", "../output/events/", "Needs to provide the summary output dir in training.")
 # additions
-flags.DEFINE_string("model", "auto", "inception_v3_head | flower_cnn | resnet50 | auto (inception on GPU, flower_cnn on CPU)")
+flags.DEFINE_string("model", "auto", "inception_v3_head | inception_v3_finetune | flower_cnn | resnet50 | auto (inception on GPU, flower_cnn on CPU)")
 flags.DEFINE_integer("batch_size", 32, "Training batch size (the reference hard-codes 32).")
 flags.DEFINE_float("learning_rate", 0.001, "Initial learning rate of the exponential decay schedule.")
 flags.DEFINE_float("head_dropout_rate", 0.5, "Drop probability of the head dropout (the reference feeds 0.5).")
@@ -99,8 +99,12 @@ def main(argv):
 
     batch_size = min(FLAGS.batch_size, len(train))
     n_iterations_per_epoch = max(1, len(train) // batch_size)
-    kw = {"head_dropout_rate": FLAGS.head_dropout_rate, "trunk_bn": FLAGS.trunk_bn} if model_name == "inception_v3_head" else (
-        {"dropout_rate": FLAGS.head_dropout_rate} if model_name == "flower_cnn" else {})
+    if model_name == "inception_v3_head":
+        kw = {"head_dropout_rate": FLAGS.head_dropout_rate, "trunk_bn": FLAGS.trunk_bn}
+    elif model_name == "inception_v3_finetune":  # the trunk is trained as well (beyond the reference's var_list=fc_vars)
+        kw = {"head_dropout_rate": FLAGS.head_dropout_rate}
+    else:
+        kw = {"dropout_rate": FLAGS.head_dropout_rate} if model_name == "flower_cnn" else {}
     model = build_model(model_name, num_classes=len(flower_classes), device=device, **kw)
     engine = DataParallelEngine(model, mode="sync_dp", optimizer="adam",
                                 lr=exponential_decay(FLAGS.learning_rate, decay_steps=200, decay_rate=0.95))

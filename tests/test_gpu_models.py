@@ -184,6 +184,57 @@ def test_inception_head_gradient_matches_cpu_autograd():
     assert all(p.grad is None for p in model.trunk.parameters())
 
 
+def test_inception_finetune_matches_cpu_reference_and_learns():
+    """``inception_v3_finetune`` trains the trunk too: loss and the gradients of all trunk and head variables of one
+    training step against fp32 CPU autograd, judged against PyTorch's own bf16 GPU ops on the same network (the
+    calibration of ``test_forward_backward_matches_cpu_reference``); the variables no loss touches (AuxLogits,
+    Logits) receive no gradient; a few Adam steps on a fixed batch reduce the loss."""
+    torch.manual_seed(0)
+    cpu = build_model("inception_v3_finetune", device="cpu", head_dropout_rate=0.0).train()
+    cpu.trunk.prelogits_dropout_rate = 0.0
+    for p in cpu.parameters():
+        if p.dim() > 1:
+            p.data = p.data.bfloat16().float()
+    gpu = cast_for_device(copy.deepcopy(cpu), "cuda").train()
+    gpu_ref = cast_for_device(copy.deepcopy(cpu), "cuda").train()
+    x, y = _images(8, 139, seed=5)
+    xb = x.bfloat16()
+
+    def run(model, xin, yin):
+        logits, reg = model(xin)
+        loss, _, _, _ = F.softmax_xent(logits, yin, 5, act_l2=model.head.act_l2)
+        (loss + reg).backward()
+        return (loss + reg).item()
+
+    loss_c = run(cpu, xb.float(), y)
+    loss_g = run(gpu, xb.cuda(), y.cuda().to(torch.int32))
+    with F.reference_mode():
+        loss_r = run(gpu_ref, xb.cuda(), y.cuda().to(torch.int32))
+    assert abs(loss_c - loss_g) <= 1.5 * abs(loss_c - loss_r) + 0.01 * abs(loss_c), (loss_c, loss_g, loss_r)
+    gc, gg, gr = _grads_by_name(cpu), _grads_by_name(gpu), _grads_by_name(gpu_ref)
+    assert gc.keys() == gg.keys()
+    assert any(n.startswith("trunk.Conv2d_1a_3x3") for n in gc) and any(n.startswith("trunk.Mixed_7c") for n in gc)
+    assert not any("AuxLogits" in n or "Logits_Conv2d_1c_1x1" in n for n in gg)
+    whole = lambda g: torch.cat([g[n].flatten() for n in gc])
+    vc, vg, vr = whole(gc), whole(gg), whole(gr)
+    err_hip, err_lib = ((vc - vg).norm() / vc.norm()).item(), ((vc - vr).norm() / vc.norm()).item()
+    assert err_hip <= 1.2 * err_lib + 0.02, (err_hip, err_lib)
+
+    eng = DataParallelEngine(gpu, mode="sync_dp", optimizer="adam", lr=1e-3)
+    xg, yg = xb.cuda(), y.cuda().to(torch.int32)
+    before = gpu.trunk.Mixed_5b.b0.weight.detach().clone()
+    losses = []
+    for _ in range(12):
+        eng.begin_step()
+        logits, reg = gpu(xg)
+        loss, _, _, _ = F.softmax_xent(logits, yg, 5, act_l2=gpu.head.act_l2)
+        (loss + reg).backward()
+        eng.finish_step()
+        losses.append(loss.item())
+    assert not torch.equal(before, gpu.trunk.Mixed_5b.b0.weight)
+    assert losses[-1] < 0.5 * losses[0], losses
+
+
 def test_step_graph_matches_eager():
     """A step replayed from a HIP graph is the same arithmetic as the eager step (deterministic kernels,
     no dropout in this model): parameters agree bit for bit after several steps."""
