@@ -55,6 +55,11 @@ struct ConvArgs {
   // stat_acc[0..Cout) (sum) and stat_acc[Cout..2 Cout) (sum of squares), fp64, zeroed by the caller.  For launches of
   // few tiles, where a separate reduction kernel per layer costs as much as the layer (see bn_apply_sums).
   double* stat_acc;
+  // A layer may be covered by two launches with different tiles (the last, partly filled round of large tiles
+  // re-cut into small ones): this launch covers tile_m_count row tiles from tile_m_base on (in units of its own
+  // tile height, 128 rows for the macro tiles; count 0 = up to the last), and its first row of partial statistics
+  // is stat_row_base.
+  int tile_m_base, tile_m_count, stat_row_base;
 };
 
 #define MAX_TAPS 64
@@ -269,7 +274,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
           unsafeAtomicAdd(p.stat_acc + co, (double)t1);
           unsafeAtomicAdd(p.stat_acc + p.Cout + co, (double)t2);
         } else {
-          const size_t prow = (size_t)tile_m * 2;
+          const size_t prow = ((size_t)tile_m - p.tile_m_base + p.stat_row_base) * 2;
           p.stats[prow * p.Cout + co] = t1;
           p.stats[(prow + 1) * p.Cout + co] = t2;
         }
@@ -449,7 +454,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
     const bool reader = t < BN && n0 + t < p.Cout && valid;
     const int cwc = t / WN, cc = t % WN;
     const int at = (cc >> 3) * 8 + (cc & 7);
-    const size_t prow = (size_t)tile_m * 2;
+    const size_t prow = ((size_t)tile_m - p.tile_m_base + p.stat_row_base) * 2;
     auto park = [&](const f32x2 (&v)[4], int plane_off) {
       *(f32x4*)(red + plane_off + lane * 8) = f32x4{v[0].x, v[0].y, v[1].x, v[1].y};
       *(f32x4*)(red + plane_off + lane * 8 + 4) = f32x4{v[2].x, v[2].y, v[3].x, v[3].y};

@@ -77,10 +77,11 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
   const int wr = wid >> 1, wc = wid & 1;
 
   const unsigned mtiles = (p.M + BM - 1) / BM;
-  const unsigned mgroups = (mtiles + WG - 1) / WG;
+  // this launch covers tile_m_count row tiles from tile_m_base on (0: all that follow)
+  const unsigned mgroups = ((p.tile_m_count > 0 ? (unsigned)p.tile_m_count : mtiles - p.tile_m_base) + WG - 1) / WG;
   const unsigned ntiles = (p.Cout + BN - 1) / BN;
   const unsigned bid = xcd_remap(blockIdx.x, mgroups * ntiles);
-  const unsigned tile_m = (bid / ntiles) * WG + grp, tile_n = bid % ntiles;
+  const unsigned tile_m = p.tile_m_base + (bid / ntiles) * WG + grp, tile_n = bid % ntiles;
   const bool valid = tile_m < mtiles;   // the last macro tile may have a group without rows
   const int m0 = valid ? (int)(tile_m * BM) : p.M, n0 = tile_n * BN;
 
@@ -371,7 +372,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   constexpr int STAGE = (WG * BM + BN) * ROWB;
   constexpr int EP = WG * (4 * (BM / 2) * ((BN / 2) * 2 + 16) + 2 * (BN / 2) * 2 * 4);  // row tiles + statistics exchange
   size_t lds = MAX_TAPS * 4 + (size_t)((NST * STAGE > EP) ? NST * STAGE : EP);
-  unsigned mtiles = (a.M + BM - 1) / BM, ntiles = (a.Cout + BN - 1) / BN;
+  unsigned mtiles = a.tile_m_count > 0 ? (unsigned)a.tile_m_count : (a.M + BM - 1) / BM - a.tile_m_base;
+  unsigned ntiles = (a.Cout + BN - 1) / BN;
   unsigned mgroups = (mtiles + WG - 1) / WG;
   // the dynamic-LDS limit is a per-device function attribute: remember it per device, not per process
   static bool attr_set[64] = {};
@@ -436,6 +438,13 @@ extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int ns
   if ((a->oscale != nullptr || a->ldo != a->Cout) && (a->stats != nullptr || a->bn_y != nullptr)) return -6;
   if (a->ldo != a->Cout && a->addend != nullptr && !fwd_residual) return -6;
   if (a->M <= 0) return 0;
+  {
+    const int unit = bm == 256 ? 128 : bm;   // tile_m_base counts the kernel's own row tiles (128 rows for the macro tiles)
+    if (a->tile_m_base < 0 || a->tile_m_count < 0 || a->stat_row_base < 0 ||
+        ((long long)a->tile_m_base + (a->tile_m_count > 0 ? a->tile_m_count - 1 : 0)) * unit >= a->M)
+      return -9;
+    if (a->tile_m_count > 0 && bm == 256 && (a->tile_m_count & 1)) return -9;   // whole macro tiles
+  }
   // bm == 256: two wave groups of 128 rows sharing one weight tile
   if (bm == 256 && bn == 128 && bk == 32 && nst == 3) return launch_conv_epi<128, 128, 32, 3, 2>(*a, stream);
   if (bm == 256 && bn == 128 && bk == 32 && nst == 2) return launch_conv_epi<128, 128, 32, 2, 2>(*a, stream);

@@ -383,6 +383,7 @@ static int launch_pro_tile(const ConvArgs& a, const ProArgs& q, int bn, int bk, 
 extern "C" int dtfa_conv_pro(const ConvArgs* a, const ProArgs* q, int pro, int bn, int bk, hipStream_t stream) {
   if (a->Cin % 8 != 0 || a->Cout % 8 != 0 || a->T != 1 || a->K != a->Cin) return -1;
   if (!a->pointwise || !a->dense_out || a->ldo != a->Cout) return -2;
+  if (a->tile_m_base != 0 || a->tile_m_count != 0 || a->stat_row_base != 0) return -2;   // one launch covers the whole layer here
   if (a->bias != nullptr || a->relu || a->oscale != nullptr) return -4;
   if (a->addend != nullptr && a->stats != nullptr && a->bn_y == nullptr) return -4;
   if (a->bn_y != nullptr) {

@@ -208,7 +208,42 @@ def pick_fwd_tile(M: int, cout: int, K: int, dense: bool = True) -> Tuple[int, i
     return bm, bn, bk, (2 if bk == 64 else 3)
 
 
+# Tail re-cut.  The macro tiles run one (256 x 256) or two (256 x 128) workgroups per CU, so a launch is a sequence of
+# rounds of 256 / 512 tiles, and a last round that fills a fraction of the chip still lasts a whole round: at batch
+# 2048 the 7x7 512 -> 512 layers are 784 tiles = 3.06 rounds (measured: 505 us against 429 us for the 768 tiles of
+# batch 2006; with the tail re-cut 444 us), the 14x14 256 -> 256 layers 6.125 (504 -> 472 us).  When the last round would be at most ``_TAIL_MAX`` full, the rows of
+# that round are given to a second launch with the tile ``pick_fwd_tile`` chooses for a layer of just those rows
+# (small tiles, several workgroups per CU: a fraction of a round).
+_TAIL = os.environ.get("DTFA_CONV_TAIL", "1") == "1"
+_TAIL_MAX = float(os.environ.get("DTFA_CONV_TAIL_MAX", "0.6"))
+_TAIL_MAX_ROUNDS = int(os.environ.get("DTFA_CONV_TAIL_MAX_ROUNDS", "8"))
+
+
+def split_tail(M: int, cout: int, K: int, bm: int, bn: int, dense: bool):
+    """(rows of the main launch, tile of the tail launch or None)."""
+    if not _TAIL or bm != 256 or _env_tile("DTFA_CONV_TILE"):
+        return M, None
+    slots = 256 if bn == 256 else 512
+    nt = -(-cout // bn)
+    tiles = -(-M // bm) * nt
+    full = tiles // slots
+    rem = tiles - full * slots
+    if full < 1 or full > _TAIL_MAX_ROUNDS or rem == 0 or rem > _TAIL_MAX * slots:
+        return M, None   # (beyond a handful of rounds the fraction saved is within the noise: measured at 12 and 24)
+    m_main = (full * slots // nt) * bm
+    if m_main <= 0 or m_main >= M:
+        return M, None
+    tbm, tbn, tbk, tnst = pick_fwd_tile(M - m_main, cout, K, dense)
+    if m_main % (128 if tbm == 256 else tbm):
+        return M, None
+    return m_main, (tbm, tbn, tbk, tnst)
+
+
 _WGRAD_WIDE = os.environ.get("DTFA_WGRAD_WIDE", "1") == "1"
+# weight-gradient instantiation -> (workgroups resident per CU, rounds of them a layer with taps is split into)
+_WGRAD_RESIDENT = {(256, 128, 32): (2, 4), (128, 256, 32): (2, 4), (64, 256, 32): (2, 4), (128, 128, 32): (3, 3),
+                   (64, 128, 32): (4, 3), (128, 64, 32): (4, 3), (64, 64, 32): (6, 4), (128, 128, 64): (2, 4),
+                   (64, 128, 64): (3, 3), (128, 64, 64): (3, 3), (64, 64, 64): (5, 4)}
 
 
 def pick_wgrad_tile(M: int, cout: int, K: int, cin: int = 0) -> Tuple[int, int, int, int]:
@@ -238,12 +273,19 @@ def pick_wgrad_tile(M: int, cout: int, K: int, cin: int = 0) -> Tuple[int, int, 
     # CU (one when a single large tile covers the whole gradient: -5 .. 12 % against four per CU); layers with taps
     # re-read their operands from cache, run at a lower rate per workgroup, and want eight per CU.
     if K != cin or cin <= 0:
-        want = 2048
-    elif tiles <= 2 and bmw * bnw >= 128 * 128:
-        want = 256
+        # whole rounds of resident workgroups: a last round that fills a fraction of the slots runs as long as a full
+        # one.  Slots per CU follow from the registers and LDS of each instantiation; rounds measured at batch 2048 /
+        # 1024 over the ResNet-50 and flower CNN layers (tools/dev/bench_wgrad_rounds.py): four for the 64 x 64 tile
+        # (56x56 3x3 64->64: -25 % against 1.3 rounds, 112x112 32->64: -21 % against 3.3), three for 128 x 128
+        # (-5 %), and for the 256-wide tiles one round per nine output tiles up to four (-5 .. 13 %)
+        per_cu, rounds = _WGRAD_RESIDENT.get((bmw, bnw, bkp), (2, 4))
+        if bmw == 256 or bnw == 256:
+            rounds = max(1, min(4, (tiles + 4) // 9))
+        want = 256 * per_cu * rounds if cin > 16 else 2048   # (image-like inputs: the stems keep their measured count)
+        splits = max(1, min(want // tiles, max(1, kt_total // 8), 4096))
     else:
-        want = 512
-    splits = max(1, min(-(-want // tiles), max(1, kt_total // 8), 1024))
+        want = 256 if (tiles <= 2 and bmw * bnw >= 128 * 128) else 512
+        splits = max(1, min(-(-want // tiles), max(1, kt_total // 8), 1024))
     if forced and len(forced) > 3:
         splits = forced[3]
     return bmw, bnw, bkp, splits
@@ -265,9 +307,11 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     dense_out = osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow
     bm, bn, bk, nst = pick_fwd_tile(M, cout, K, dense_out)
     L = hipk.lib()
+    # rows covered by the main launch; the rest (the tail of a partly filled last round of macro tiles) is re-cut
+    m_main, tail = split_tail(M, cout, K, bm, bn, dense_out) if stat_acc is None else (M, None)
     part = None
     if stats or bn_tap is not None:
-        rows = L.dtfa_conv_stats_rows(M, bm)
+        rows = L.dtfa_conv_stats_rows(m_main, bm) + (L.dtfa_conv_stats_rows(M - m_main, tail[0]) if tail else 0)
         part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
     a = hipk.ConvArgs()
     a.x, a.w, a.y = x.data_ptr(), w2d.data_ptr(), y.data_ptr()
@@ -301,8 +345,17 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     # 1x1 / stride 1 / no padding: input pixel index == output pixel index, the kernel skips the pixel decode
     a.pointwise = 1 if (zero_taps and a.dense_out and T == 1 and isy == 1 and isx == 1
                         and ih == oyn and iw == oxn) else 0
+    if tail is not None:
+        a.tile_m_count = m_main // (128 if bm == 256 else bm)
     hipk.check(L.dtfa_conv_igemm(C.byref(a), bm, bn, bk, nst, hipk.stream()),
                "conv_igemm %dx%dx%d/%d" % (bm, bn, bk, nst))
+    if tail is not None:
+        tbm, tbn, tbk, tnst = tail
+        a.tile_m_count = 0
+        a.tile_m_base = m_main // (128 if tbm == 256 else tbm)
+        a.stat_row_base = L.dtfa_conv_stats_rows(m_main, bm)
+        hipk.check(L.dtfa_conv_igemm(C.byref(a), tbm, tbn, tbk, tnst, hipk.stream()),
+                   "conv_igemm tail %dx%dx%d/%d" % (tbm, tbn, tbk, tnst))
     return part
 
 

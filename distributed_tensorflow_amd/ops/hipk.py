@@ -36,6 +36,7 @@ class ConvArgs(C.Structure):
         ("bn_mask", c_void), ("bn_relu", c_int),
         ("ldo", c_int), ("oscale", c_void), ("stream_out", c_int), ("omask", c_void), ("dbias", c_void), ("bn_gate_store", c_int),
         ("x2", c_void), ("K1", c_int), ("addend_shy", c_int), ("addend_shx", c_int), ("stat_acc", c_void),
+        ("tile_m_base", c_int), ("tile_m_count", c_int), ("stat_row_base", c_int),
     ]
 
 

@@ -144,6 +144,53 @@ def test_conv_large_tiles():
     assert (dw.cpu() - wr.grad).abs().max().item() <= 2e-2 * wr.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("case", [(10, 64, 128, 512, 256, 1, 1, 1, 1, "VALID"), (12, 102, 128, 32, 128, 3, 3, 1, 1, "SAME")])
+def test_tail_of_last_round_recut_into_small_tiles(case, monkeypatch):
+    """A layer whose macro tiles fill whole rounds of the chip plus a fraction of one is covered by two launches
+    (the rows of the fraction re-cut into small tiles).  Outputs are the bits of the single launch; the partial
+    statistics rows of both launches add up to the same column sums; the same holds for a data gradient that
+    emits batch-norm backward sums and adds a residual gradient."""
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case, 11)
+    xb, wb = x.bfloat16().cuda(), w.bfloat16().cuda()
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    M = B * plan.oh * plan.ow
+    tile = cv.pick_fwd_tile(M, Cout, plan.K, True)
+    m_main, tail = cv.split_tail(M, Cout, plan.K, tile[0], tile[1], True)
+    assert tail is not None and 0 < m_main < M, (tile, m_main, tail)
+    y2, part2 = cv.conv_fwd(xb, wb, plan, want_stats=True)
+    g = torch.Generator().manual_seed(12)
+    dy = torch.randn(B, plan.oh, plan.ow, Cout, generator=g).bfloat16().cuda()
+    addend = torch.randn(B, H, W, Cin, generator=g).bfloat16().cuda()
+
+    def dgrad():
+        tap = cv.BnBackwardTap()
+        gg = torch.Generator().manual_seed(13)
+        tap.y = torch.randn(B, H, W, Cin, generator=gg).bfloat16().cuda()
+        tap.mean = torch.randn(Cin, generator=gg).cuda() * 0.1
+        tap.invstd = (torch.rand(Cin, generator=gg) + 0.5).cuda()
+        tap.scale = (torch.rand(Cin, generator=gg) + 0.5).cuda()
+        tap.shift = torch.randn(Cin, generator=gg).cuda() * 0.2
+        tap.mask = None
+        tap.relu_mode = 2
+        dx = cv.conv_dgrad(dy, wb, plan, addend=addend, bn_tap=tap)
+        return dx, tap.partials
+
+    dx2, bp2 = dgrad()
+    monkeypatch.setattr(cv, "_TAIL", False)
+    y1, part1 = cv.conv_fwd(xb, wb, plan, want_stats=True)
+    dx1, bp1 = dgrad()
+    assert torch.equal(y1, y2)
+    assert torch.equal(dx1, dx2)
+    assert part2.shape[0] != part1.shape[0] or tail[0] >= 128
+    torch.testing.assert_close(part2.double().sum(0), part1.double().sum(0), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(bp2.double().sum(0), bp1.double().sum(0), rtol=1e-5, atol=1e-3)
+    # and against the fp32 definition on a slice of rows that spans the boundary between the two launches
+    b0 = m_main // (plan.oh * plan.ow)
+    want = ref.conv2d(xb[b0:b0 + 1].float().cpu(), wb.float().cpu(), (sy, sx), pads)
+    torch.testing.assert_close(y2[b0:b0 + 1].float().cpu(), want, rtol=2e-2, atol=2e-2)
+
+
 def test_dgrad_masked_addend():
     """The dgrad epilogue adds only the elements of ``addend`` whose bit is set."""
     case = (2, 14, 14, 64, 32, 1, 1, 1, 1, "VALID")

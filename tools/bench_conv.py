@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--reference", action="store_true")
-    ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--only", default="", help="comma-separated row indices of the shape table (default: all rows)")
     ap.add_argument("--shapes", default="resnet", choices=["resnet", "inception", "flower"])
     ap.add_argument("--fwd_only", action="store_true")
     args = ap.parse_args()
@@ -109,8 +109,9 @@ def main():
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0, "ref_fwd": 0.0, "ref_bwd": 0.0}
     print("%-28s %8s | %8s %7s | %8s %7s | %8s %7s" % ("shape", "GFLOP", "fwd us", "TF/s", "dgrad us", "TF/s", "wgrad us", "TF/s"))
     table = {"resnet": RESNET, "inception": INCEPTION, "flower": FLOWER}[args.shapes]
+    only = {int(v) for v in args.only.split(",") if v.strip()}
     for i, shape in enumerate(table):
-        if args.only >= 0 and i != args.only:
+        if only and i not in only:
             continue
         H, W, Cin, Cout, (kh, kw), s, pads, weight = normalise(shape)
         pad = pads[0]
