@@ -40,6 +40,23 @@
 #ifndef CONV_INTERLEAVE
 #define CONV_INTERLEAVE 2
 #endif
+// 1: the LDS-DMA requests of a k-tile are issued one behind each MFMA of the tile's first k-step (the address
+// arithmetic and the issue slots of a request then sit in the shadow of a running MFMA); 0: all of them in one burst
+// ahead of the k-tile's first MFMA, during which neither wave of a SIMD feeds the matrix pipe.  (1: the 256 x 256
+// macro tile only, 2: every tile.)  Measured at batch 2048 -- profiles/conv_pmc.md: +-3 % on the 256 x 256 tile, slower
+// on the others (the requests' live state costs 10 - 19 registers, which takes a resident workgroup from the
+// 256 x 128 macro tile), so the burst stays.
+#ifndef CONV_SPREAD
+#define CONV_SPREAD 0
+#endif
+// Two-stage tiles: 0 = k-tile kt+1 is requested at the top of k-tile kt (into the slot whose last reads completed
+// before the previous barrier); 1 = it is requested one MFMA group earlier, right behind that barrier and ahead of
+// the last MFMAs of k-tile kt-1 (every fragment of the slot is in registers by then), so the LDS-DMA path also works
+// during that group and a k-tile has a third more time to land; 2 = the same with the requests spread over the
+// group's MFMAs.  Measured: -3 .. 6 % on the 7x7 / 14x14 pointwise layers, +3 % on 14x14 3x3, i.e. no consistent gain.
+#ifndef CONV_LATE
+#define CONV_LATE 0
+#endif
 // workgroups per CU the narrow (<= 128 x 64) tiles are compiled for
 #ifndef CONV_NARROW_OCC
 #define CONV_NARROW_OCC 3
@@ -136,39 +153,50 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
 
   if (!pointwise) __syncthreads();  // tap table visible
 
-  auto stage = [&](int kt, int buf) {
-    char* sa = lds_tiles + buf * STAGE + grp * (BM * ROWB);
-    char* sb = lds_tiles + buf * STAGE + WG * BM * ROWB;
-    const int kc8 = kt * BK + cslot * 8;
-    const bool kvalid = kc8 < p.K;
-    if (pointwise) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const bf16* src = (kvalid && aiy[i] == 0) ? (kc8 < K1 ? abase[i] : abase2[i]) + kc8 : p.zero;
-        glds16(src, sa + (i * 4 + wid) * 1024);
-      }
-    } else {
-      const int tap = (int)__umulhi((unsigned)kc8, p.cin_magic);
-      const int ci = kc8 - tap * p.Cin;
-      const int tp = kvalid ? lds_taps[tap] : 0;
-      const int dy = tp >> 16;
-      const int dx = (int)(short)(tp & 0xffff);
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        int iy = aiy[i] + dy, ix = aix[i] + dx;
-        bool ok = kvalid && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+  // One k-tile's requests: ``stage_begin`` fixes the tile (destination slot, reduction chunk, tap), ``stage_piece(j)``
+  // issues request j of NA + NBW (the pixel rows first, then this wave's share of the weight rows).
+  char* st_sa = nullptr;
+  char* st_sb = nullptr;
+  int st_kc8 = 0, st_ci = 0, st_dy = 0, st_dx = 0;
+  bool st_kvalid = false;
+  auto stage_begin = [&](int kt, int buf) {
+    st_sa = lds_tiles + buf * STAGE + grp * (BM * ROWB);
+    st_sb = lds_tiles + buf * STAGE + WG * BM * ROWB;
+    st_kc8 = kt * BK + cslot * 8;
+    st_kvalid = st_kc8 < p.K;
+    if (!pointwise) {
+      const int tap = (int)__umulhi((unsigned)st_kc8, p.cin_magic);
+      st_ci = st_kc8 - tap * p.Cin;
+      const int tp = st_kvalid ? lds_taps[tap] : 0;
+      st_dy = tp >> 16;
+      st_dx = (int)(short)(tp & 0xffff);
+    }
+  };
+  auto stage_piece = [&](int j) {
+    if (j < NA) {
+      const int i = j;
+      const bf16* src;
+      if (pointwise) {
+        src = (st_kvalid && aiy[i] == 0) ? (st_kc8 < K1 ? abase[i] : abase2[i]) + st_kc8 : p.zero;
+      } else {
+        int iy = aiy[i] + st_dy, ix = aix[i] + st_dx;
+        bool ok = st_kvalid && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
         // element offset inside the image with two full-rate 24-bit multiplies (the launcher checks
         // IH * IW < 2^24 and IH * IW * Cin < 2^32); the 64-bit form costs two quarter-rate multiplies per row
-        const unsigned off = __umul24(__umul24((unsigned)iy, (unsigned)p.IW) + (unsigned)ix, (unsigned)p.Cin) + (unsigned)ci;
-        const bf16* src = ok ? abase[i] + off : p.zero;
-        glds16(src, sa + (i * 4 + wid) * 1024);
+        const unsigned off = __umul24(__umul24((unsigned)iy, (unsigned)p.IW) + (unsigned)ix, (unsigned)p.Cin) + (unsigned)st_ci;
+        src = ok ? abase[i] + off : p.zero;
       }
+      glds16(src, st_sa + (i * 4 + wid) * 1024);
+    } else {
+      const int i = j - NA;
+      const bf16* src = (st_kvalid && bok[i]) ? bbase[i] + st_kc8 : p.zero;
+      glds16(src, st_sb + (i * 4 * WG + wid_all) * 1024);
     }
+  };
+  auto stage = [&](int kt, int buf) {
+    stage_begin(kt, buf);
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-      const bf16* src = (kvalid && bok[i]) ? bbase[i] + kc8 : p.zero;
-      glds16(src, sb + (i * 4 * WG + wid_all) * 1024);
-    }
+    for (int j = 0; j < NA + NBW; ++j) stage_piece(j);
   };
 
   // ---- fragment read offsets ----
@@ -207,6 +235,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
   // Within a tile the fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks run, and
   // the first fragments of tile kt+1 are read behind the barrier, ahead of the last MFMAs of tile kt.
   static_assert(NST == 2 || NST == 3, "two or three LDS stages");
+  constexpr bool LATE = CONV_LATE != 0 && NST == 2 && CONV_INTERLEAVE == 2;
   stage(0, 0);
   if (NST == 3 && KT > 1) {
     stage(1, 1);
@@ -215,6 +244,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
     wait_vmcnt<0>();
   }
   __syncthreads();
+  if (LATE && KT > 1 && !(DTFA_DBG & 1)) stage(1, 1);
 
   bf16x8 af[2][MT], bfr[2][NT];
 #if (DTFA_DBG & 4)
@@ -254,12 +284,23 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
 #endif
   };
 
-  // MFMAs of fragment set ``src`` with the reads of (buf, ks) into set ``dst`` issued one behind each MFMA
-  auto mfma_read_step = [&](int src, int buf, int ks, int dst, bool do_read) {
-    if (!wave_live) return;
+  // MFMAs of fragment set ``src`` with the reads of (buf, ks) into set ``dst`` issued one behind each MFMA; with
+  // ``do_stage`` the requests of the k-tile prepared by ``stage_begin`` go out one behind each MFMA as well
+  auto mfma_read_step = [&](int src, int buf, int ks, int dst, bool do_read, bool do_stage) {
+    if (!wave_live) {
+      if (do_stage) {
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) stage_piece(j);
+      }
+      return;
+    }
 #if (DTFA_DBG & 6)
     mfma_step(src);
     if (do_read) read_frags(buf, ks, dst);
+    if (do_stage) {
+#pragma unroll
+      for (int j = 0; j < LPS; ++j) stage_piece(j);
+    }
 #else
     const char* base = lds_tiles + buf * STAGE;
     const int sl = ks * 2 + khalf;
@@ -275,6 +316,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
           if (i < MT) af[dst][i] = *(const bf16x8*)(base + aoff[i] + ((sl ^ aswz[i]) << 4));
           else if (i < MT + NT) bfr[dst][i - MT] = *(const bf16x8*)(base + boff[i - MT] + ((sl ^ bswz[i - MT]) << 4));
         }
+        if (do_stage && i < LPS) stage_piece(i);
         __builtin_amdgcn_sched_barrier(0);
       }
     // tiles with fewer MFMAs than fragments (a single MFMA per k-step): the remaining reads
@@ -285,6 +327,10 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
         else bfr[dst][i - MT] = *(const bf16x8*)(base + boff[i - MT] + ((sl ^ bswz[i - MT]) << 4));
       }
     }
+    if (do_stage) {   // ... and the remaining requests
+#pragma unroll
+      for (int j = MT * NT; j < LPS; ++j) stage_piece(j);
+    }
     __builtin_amdgcn_s_setprio(0);
 #endif
   };
@@ -294,7 +340,14 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
   for (int kt = 0; kt < KT; ++kt) {
     const int nxt = cur == NST - 1 ? 0 : cur + 1;
     // the slot requested here held tile kt-1, which every wave finished reading before the last barrier
-    if (kt + NST - 1 < KT && !(DTFA_DBG & 1)) stage(kt + NST - 1, NST == 2 ? nxt : (nxt == 2 ? 0 : nxt + 1));
+    const bool do_stage = !LATE && kt + NST - 1 < KT && !(DTFA_DBG & 1);
+    // (CONV_SPREAD 1: the 256 x 256 macro tile only -- one workgroup per CU, so nothing else feeds the matrix pipe during
+    // a burst of eight requests per thread, and it has the registers for the requests' live state; 2: every tile)
+    constexpr bool SPREAD = CONV_INTERLEAVE == 2 && (CONV_SPREAD == 2 || (CONV_SPREAD == 1 && WG == 2 && BN == 256));
+    if (do_stage) {
+      if (SPREAD) stage_begin(kt + NST - 1, NST == 2 ? nxt : (nxt == 2 ? 0 : nxt + 1));
+      else stage(kt + NST - 1, NST == 2 ? nxt : (nxt == 2 ? 0 : nxt + 1));
+    }
 #pragma unroll
     for (int ks = 0; ks + 1 < KS; ++ks) {
 #if CONV_INTERLEAVE
@@ -302,7 +355,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
       // MFMAs: an MFMA group waits only for fragments requested a whole k-step earlier.  With the reads issued
       // BEFORE the MFMAs, the compiler's lgkmcnt(0) in front of the group waited for the fresh reads as well.
 #if CONV_INTERLEAVE == 2
-      mfma_read_step(ks & 1, cur, ks + 1, (ks + 1) & 1, true);
+      mfma_read_step(ks & 1, cur, ks + 1, (ks + 1) & 1, true, SPREAD && do_stage && ks == 0);
       __builtin_amdgcn_sched_barrier(0);
 #else
       mfma_step(ks & 1);
@@ -331,7 +384,13 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
 #endif
     }
 #if CONV_INTERLEAVE == 2
-    mfma_read_step((KS - 1) & 1, nxt, 0, 0, kt + 1 < KT);
+    // (LATE: tile kt's slot is free behind the barrier -- its last fragments are in registers -- and takes tile kt+2)
+    const bool late_stage = LATE && kt + 2 < KT && !(DTFA_DBG & 1);
+    if (late_stage) {
+      if (CONV_LATE == 2) stage_begin(kt + 2, cur);
+      else stage(kt + 2, cur);
+    }
+    mfma_read_step((KS - 1) & 1, nxt, 0, 0, kt + 1 < KT, CONV_LATE == 2 && late_stage);
     __builtin_amdgcn_sched_barrier(0);
 #else
     mfma_step((KS - 1) & 1);
