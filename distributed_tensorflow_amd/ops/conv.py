@@ -240,6 +240,7 @@ def split_tail(M: int, cout: int, K: int, bm: int, bn: int, dense: bool):
 
 
 _WGRAD_WIDE = os.environ.get("DTFA_WGRAD_WIDE", "1") == "1"
+_WGRAD_ROUNDS = os.environ.get("DTFA_WGRAD_ROUNDS", "1") == "1"
 # weight-gradient instantiation -> (workgroups resident per CU, rounds of them a layer with taps is split into)
 _WGRAD_RESIDENT = {(256, 128, 32): (2, 4), (128, 256, 32): (2, 4), (64, 256, 32): (2, 4), (128, 128, 32): (3, 3),
                    (64, 128, 32): (4, 3), (128, 64, 32): (4, 3), (64, 64, 32): (6, 4), (128, 128, 64): (2, 4),
@@ -283,6 +284,8 @@ def pick_wgrad_tile(M: int, cout: int, K: int, cin: int = 0) -> Tuple[int, int, 
             rounds = max(1, min(4, (tiles + 4) // 9))
         want = 256 * per_cu * rounds if cin > 16 else 2048   # (image-like inputs: the stems keep their measured count)
         splits = max(1, min(want // tiles, max(1, kt_total // 8), 4096))
+        if not _WGRAD_ROUNDS:   # the rule this replaced: 2048 workgroups whatever the tile
+            splits = max(1, min(-(-2048 // tiles), max(1, kt_total // 8), 1024))
     else:
         want = 256 if (tiles <= 2 and bmw * bnw >= 128 * 128) else 512
         splits = max(1, min(-(-want // tiles), max(1, kt_total // 8), 1024))
