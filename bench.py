@@ -169,9 +169,16 @@ def main():
 
     also = {}
 
+    import threading
+
+    report_lock = threading.Lock()
+    reported = []
+
     def report():
-        if rank != 0:
-            return
+        with report_lock:   # (the watchdog and the main thread may get here together: one line, once)
+            if reported or rank != 0:
+                return
+            reported.append(True)
         print(json.dumps({
             "metric": "train images/sec (whole node)",
             "value": head["value"],
@@ -200,8 +207,6 @@ def main():
     # The headline number is measured; the secondary runs below must not be able to lose it.  If one of them
     # hangs (a rank that failed inside a collective leaves its peers waiting), the watchdog reports the headline
     # with whatever secondary results exist and ends the process.
-    import threading
-
     done = threading.Event()
 
     def watchdog():
