@@ -40,7 +40,7 @@ IMAGE_SIZE = {"resnet50": 224, "flower_cnn": 224, "inception_v3_head": 299, "inc
 def run_config(args, model_name, batch, device, rank, world, mode=None):
     """W untimed + K timed complete training steps of one model; returns the whole-job images/s (max time over ranks)."""
     mode = mode or args.mode
-    size = IMAGE_SIZE[model_name]
+    size = args.image_size or IMAGE_SIZE[model_name]
     torch.manual_seed(1234)
     kw = {"trunk_bn": args.trunk_bn} if model_name == "inception_v3_head" else {}
     model = build_model(model_name, num_classes=5, device=device, **kw)
@@ -66,8 +66,9 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
     # image layout as the input pipeline delivers it: NHWC, 3 real channels padded to 8, or to 4 for models with the
     # pixel-pair stem (ResNet-50 on the device, data.preprocess.resize_on_device(channels=4))
     cpad = getattr(model, "input_channels", 8)
-    images = torch.zeros(batch, size, size, cpad, device=device, dtype=torch.bfloat16)
-    images[..., :3] = (torch.rand(batch, size, size, 3, device=device, generator=g) * 2 - 1).to(torch.bfloat16)
+    act = torch.bfloat16 if device.type == "cuda" else torch.float32
+    images = torch.zeros(batch, size, size, cpad, device=device, dtype=act)
+    images[..., :3] = (torch.rand(batch, size, size, 3, device=device, generator=g) * 2 - 1).to(act)
     labels = torch.randint(0, 5, (batch,), device=device, generator=g).to(torch.int32)
 
     def step():
@@ -83,7 +84,8 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
     def sync():
         if dist.is_initialized():
             dist.barrier()
-        torch.cuda.synchronize()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
 
     if args.hip_graph:
         from distributed_tensorflow_amd.train.graph import StepGraph
@@ -117,7 +119,8 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
     ips = batch * world * args.steps / dt
     return {"value": round(ips, 2), "ms_per_step": round(dt / args.steps * 1e3, 3), "final_loss": round(float(loss.item()), 4),
             "per_gpu_batch": batch, "global_batch": batch * world, "optimizer": opt,
-            "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2**30, 2), "comm": engine.comm_stats()}
+            "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2**30, 2) if device.type == "cuda" else 0.0,
+            "comm": engine.comm_stats()}
 
 
 def main():
@@ -138,8 +141,12 @@ def main():
                     help="inception_v3_head: trunk batch-norm on batch statistics (reference) or frozen moving statistics")
     ap.add_argument("--also", default="flower_cnn",
                     help="second model measured after the headline one and reported under \"also\" ('' = none)")
+    ap.add_argument("--also_batch", type=int, default=0, help="per-GPU batch of the second model (default: its own)")
     ap.add_argument("--also_modes", default="sharded_ps,async_ssp",
                     help="distribution modes the headline model is measured in as well, reported under \"also\" ('' = none)")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu: rehearse the multi-rank control flow over gloo (not a measurement)")
+    ap.add_argument("--image_size", type=int, default=0, help="square image size (default: the model's)")
     ap.add_argument("--also_timeout", type=int, default=240,
                     help="seconds the secondary (\"also\") runs may take before the headline result is reported "
                          "without them (0 = no limit)")
@@ -153,14 +160,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X GPU")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run, any N
-    if world > 1 or launched:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.device == "cpu":
+        # plumbing rehearsal only (tests/test_parallel.py): the same control flow over gloo on fp32 CPU tensors
+        device = torch.device("cpu")
+        if world > 1 or launched:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X GPU")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        if world > 1 or launched:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d; reporting WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -190,11 +204,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": "bf16" if device.type == "cuda" else "fp32 (cpu rehearsal)",
             "data": "synthetic",
             "final_loss": head["final_loss"],
             "config": {"model": args.model, "global_batch": head["global_batch"], "per_gpu_batch": head["per_gpu_batch"],
-                       "image_size": IMAGE_SIZE[args.model], "num_classes": 5, "parallelism": "dp%d" % world,
+                       "image_size": args.image_size or IMAGE_SIZE[args.model], "num_classes": 5, "parallelism": "dp%d" % world,
                        "mode": args.mode, "optimizer": head["optimizer"], "hip_graph": bool(args.hip_graph)},
             "peak_mem_gb": head["peak_mem_gb"],
             # communication of the headline run: RCCL world, gradient buckets (count / bytes each / dtype) and the
@@ -220,9 +234,10 @@ def main():
     if args.also and args.also != args.model:
         # the second model of the headline metric (flower CNN), same K / W, measured after the headline run
         gc.collect()
-        torch.cuda.empty_cache()
+        if device.type == "cuda":
+            torch.cuda.empty_cache()
         try:
-            r = run_config(args, args.also, DEFAULT_BATCH[args.also], device, rank, world)
+            r = run_config(args, args.also, args.also_batch or DEFAULT_BATCH[args.also], device, rank, world)
             also[args.also] = {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "final_loss")}
         except Exception as e:  # noqa: BLE001 -- the headline number stands on its own
             also[args.also] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -230,7 +245,8 @@ def main():
     # all-gather; staleness-bounded asynchronous updates), same batch, same K / W
     for other in [m for m in args.also_modes.split(",") if m and m != args.mode and not args.hip_graph]:
         gc.collect()
-        torch.cuda.empty_cache()
+        if device.type == "cuda":
+            torch.cuda.empty_cache()
         key = "%s/%s" % (args.model, other)
         try:
             r = run_config(args, args.model, head["per_gpu_batch"], device, rank, world, mode=other)

@@ -257,3 +257,72 @@ def test_bucket_ready_callbacks_fire_once_per_bucket():
     flat.collect_autograd_grads()
     assert sorted(fired) == sorted((g.name, b.index) for g in flat.groups for b in g.buckets)
     assert len(set(fired)) == len(fired)
+
+
+def _run_bench_cpu(world, extra, timeout=300):
+    """bench.py launched the way the driver launches it (one rank per device under torch.distributed.run), over gloo
+    on CPU tensors: the control flow of a multi-rank run -- rendezvous, barriers around the timed region, the MAX over
+    ranks, the secondary runs, one JSON line from rank 0 -- rehearsed without GPUs."""
+    import json
+    import subprocess
+    import sys
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--device", "cpu",
+           "--model", "flower_cnn", "--batch", "4", "--image_size", "32", "--steps", "2", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_over_gloo():
+    d = _run_bench_cpu(2, ["--also", "", "--also_modes", "sharded_ps,async_ssp"])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["rccl_world"] == 2
+    assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) <= 0.02 * d["value"]
+    assert d["comm"]["collective"] and d["comm"]["collectives_waited"] == 2 * d["comm"]["buckets"]
+    for mode in ("sharded_ps", "async_ssp"):
+        assert d["also"]["flower_cnn/" + mode]["value"] > 0, d["also"]
+
+
+def test_bench_reports_headline_when_secondary_runs_exceed_their_time():
+    """The watchdog: secondary runs that do not finish in ``--also_timeout`` seconds are abandoned and the headline
+    result is still printed (exactly once) with a zero exit status."""
+    d = _run_bench_cpu(2, ["--also", "resnet50", "--also_batch", "16", "--also_modes", "sharded_ps", "--also_timeout", "1"])
+    assert d["value"] > 0 and "exceeded" in d["also"].get("error", ""), d["also"]
+
+
+def test_launch_geometry_rules():
+    """Pure host logic of the two "whole rounds" rules (ops/conv.py): the tail split of macro-tile launches and the
+    weight-gradient split counts."""
+    from distributed_tensorflow_amd.ops import conv as cv
+
+    # 7x7 512 -> 512 3x3 at batch 2048: 392 x 2 tiles of 256 x 256 = 3.06 rounds of 256 -> three rounds + a tail
+    M = 2048 * 49
+    tile = cv.pick_fwd_tile(M, 512, 4608, True)
+    assert tile[:2] == (256, 256)
+    m_main, tail = cv.split_tail(M, 512, 4608, tile[0], tile[1], True)
+    assert m_main == 3 * 256 // 2 * 256 and tail is not None and tail[0] < 256
+    assert m_main % tail[0] == 0
+    # exactly three rounds: nothing to split; a last round that is mostly full: left alone
+    assert cv.split_tail(m_main, 512, 4608, 256, 256, True) == (m_main, None)
+    assert cv.split_tail(m_main + 200 * 256 // 2 * 256 // 256 * 256, 512, 4608, 256, 256, True)[1] is None
+    # less than one full round, or a tile that is not a macro tile: one launch
+    assert cv.split_tail(100 * 256, 512, 4608, 256, 256, True)[1] is None
+    assert cv.split_tail(M, 512, 4608, 128, 128, True)[1] is None
+    # weight gradient of a layer with taps: tiles x splits is a whole number of rounds of resident workgroups
+    for M_, cout, cin in [(2048 * 56 * 56, 64, 64), (2048 * 28 * 28, 128, 128), (2048 * 14 * 14, 256, 256), (2048 * 49, 512, 512)]:
+        bmw, bnw, bkp, splits = cv.pick_wgrad_tile(M_, cout, 9 * cin, cin)
+        tiles = -(-cout // bmw) * -(-9 * cin // bnw)
+        per_cu = cv._WGRAD_RESIDENT[(bmw, bnw, bkp)][0]
+        slots = 256.0 * per_cu
+        rounds = tiles * splits / slots
+        whole = -(-tiles * splits // int(slots))
+        # as many splits as fit into a whole number of rounds: one more split would start another round
+        assert 1 <= whole <= 4 and 0 <= whole - rounds < tiles / slots, (cout, bmw, bnw, splits, rounds)
