@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from . import hipk
+from . import hipk, tune
 
 
 def same_pads(size: int, k: int, s: int) -> Tuple[int, int]:
@@ -308,14 +308,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     M = B * oyn * oxn
     K = T * cin + (x2.shape[-1] if x2 is not None else 0)
     dense_out = osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow
-    bm, bn, bk, nst = pick_fwd_tile(M, cout, K, dense_out)
     L = hipk.lib()
-    # rows covered by the main launch; the rest (the tail of a partly filled last round of macro tiles) is re-cut
-    m_main, tail = split_tail(M, cout, K, bm, bn, dense_out) if stat_acc is None else (M, None)
-    part = None
-    if stats or bn_tap is not None:
-        rows = L.dtfa_conv_stats_rows(m_main, bm) + (L.dtfa_conv_stats_rows(M - m_main, tail[0]) if tail else 0)
-        part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
     a = hipk.ConvArgs()
     a.x, a.w, a.y = x.data_ptr(), w2d.data_ptr(), y.data_ptr()
     a.bias = hipk.ptr(bias)
@@ -326,7 +319,6 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
         a.bn_scale, a.bn_shift, a.bn_mask = hipk.ptr(bn_tap.scale), hipk.ptr(bn_tap.shift), hipk.ptr(bn_tap.mask)
         a.bn_relu = bn_tap.relu_mode
         a.bn_gate_store = 1 if bn_tap.gate_store else 0
-    a.stats = hipk.ptr(part)
     a.omask, a.dbias, a.x2 = hipk.ptr(omask), hipk.ptr(dbias), hipk.ptr(x2)
     a.stream_out = 1 if M * cout * 2 >= STREAM_OUT_BYTES else 0
     a.K1 = T * cin
@@ -348,18 +340,61 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     # 1x1 / stride 1 / no padding: input pixel index == output pixel index, the kernel skips the pixel decode
     a.pointwise = 1 if (zero_taps and a.dense_out and T == 1 and isy == 1 and isx == 1
                         and ih == oyn and iw == oxn) else 0
-    if tail is not None:
-        a.tile_m_count = m_main // (128 if bm == 256 else bm)
-    hipk.check(L.dtfa_conv_igemm(C.byref(a), bm, bn, bk, nst, hipk.stream()),
-               "conv_igemm %dx%dx%d/%d" % (bm, bn, bk, nst))
-    if tail is not None:
-        tbm, tbn, tbk, tnst = tail
-        a.tile_m_count = 0
-        a.tile_m_base = m_main // (128 if tbm == 256 else tbm)
-        a.stat_row_base = L.dtfa_conv_stats_rows(m_main, bm)
-        hipk.check(L.dtfa_conv_igemm(C.byref(a), tbm, tbn, tbk, tnst, hipk.stream()),
-                   "conv_igemm tail %dx%dx%d/%d" % (tbm, tbn, tbk, tnst))
-    return part
+    want_part = stats or bn_tap is not None
+
+    def launch(cfg):
+        """One configuration ``(bm, bn, bk, stages, tail)``: the main launch and, with ``tail``, the second launch
+        that re-cuts a partly filled last round (``split_tail``).  Returns the partial-statistics rows."""
+        bm, bn, bk, nst, use_tail = cfg
+        m_main, tail = (split_tail(M, cout, K, bm, bn, dense_out) if (use_tail and stat_acc is None) else (M, None))
+        part = None
+        if want_part:
+            rows = L.dtfa_conv_stats_rows(m_main, bm) + (L.dtfa_conv_stats_rows(M - m_main, tail[0]) if tail else 0)
+            part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+        a.stats = hipk.ptr(part)
+        a.tile_m_base = a.stat_row_base = 0
+        a.tile_m_count = m_main // (128 if bm == 256 else bm) if tail is not None else 0
+        hipk.check(L.dtfa_conv_igemm(C.byref(a), bm, bn, bk, nst, hipk.stream()),
+                   "conv_igemm %dx%dx%d/%d" % (bm, bn, bk, nst))
+        if tail is not None:
+            tbm, tbn, tbk, tnst = tail
+            a.tile_m_count = 0
+            a.tile_m_base = m_main // (128 if tbm == 256 else tbm)
+            a.stat_row_base = L.dtfa_conv_stats_rows(m_main, bm)
+            hipk.check(L.dtfa_conv_igemm(C.byref(a), tbm, tbn, tbk, tnst, hipk.stream()),
+                       "conv_igemm tail %dx%dx%d/%d" % (tbm, tbn, tbk, tnst))
+        return part
+
+    rule = pick_fwd_tile(M, cout, K, dense_out) + (1,)
+    cfg = rule
+    if tune.MODE != "off" and stat_acc is None and not _env_tile("DTFA_CONV_TILE"):
+        # epilogue class as the kernel dispatches it: its cost differs per tile shape, so it is part of the key
+        epi = 3 if bn_tap is not None else 1 if stats else 2 if (bias is not None or relu or oscale is not None
+                                                                   or (ldo or cout) != cout) else 0
+        key = "%d,%d,%d,%d,%d,%d,%d,%d" % (M, cout, K, T, dense_out, a.pointwise, epi, x2 is not None)
+        found = tune.lookup("igemm", key)
+        if found is None and tune.measuring() and M * cout >= _TUNE_MIN_OUT:
+            found = tune.measure("igemm", key, _igemm_candidates(M, cout, K), launch, rule)
+        if found is not None:
+            cfg = found
+    return launch(cfg)
+
+
+# configurations an autotuning run tries (tools/tune_conv.py); launches with less output than this keep the rules
+_TUNE_MIN_OUT = int(os.environ.get("DTFA_TUNE_MIN_OUT", str(1 << 22)))
+
+
+def _igemm_candidates(M: int, cout: int, K: int):
+    out = []
+    for bm, bn in ((128, 192), (128, 128), (128, 64), (64, 64)):
+        if bn >= 128 and cout <= bn // 2:
+            continue   # at least half of the tile's columns would be padding
+        out += [(bm, bn, 32, 3, 0), (bm, bn, 64, 2, 0)]
+    if cout > 64:
+        out += [(256, 128, 32, 3, 0), (256, 128, 32, 3, 1)]
+    if cout > 128 and K >= 128:
+        out += [(256, 256, 64, 2, 0), (256, 256, 64, 2, 1)]
+    return out
 
 
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[torch.Tensor] = None,
@@ -771,7 +806,6 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
     M = B * plan.oh * plan.ow
     if M >= 1 << 31 or B * plan.ih * plan.iw >= 1 << 31:
         raise ValueError("too many pixels for 32-bit indices")
-    bmw, bnw, bkp, splits = pick_wgrad_tile(M, plan.cout, plan.K, plan.cin)
     n = plan.cout * plan.K
     if colsum:
         if out is not None or not wgrad_colsum_ok(plan, M):
@@ -786,13 +820,10 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
         raise ValueError("bad wgrad output buffer")
     if out.dtype == torch.bfloat16 and accumulate:
         raise ValueError("accumulation needs an fp32 gradient buffer")
-    # an unsplit reduction (few pixels: dense layers at small batch) writes the fp32 gradient in place
-    direct = splits == 1 and out.dtype == torch.float32 and not accumulate
     per_split = n + (plan.K if colsum else 0)
-    slab = (both if colsum else out) if direct else hipk.workspace(x.device, splits * per_split * 4)
     L = hipk.lib()
     a = hipk.WgradArgs()
-    a.x, a.dy, a.slab = x.data_ptr(), dy.data_ptr(), slab.data_ptr()
+    a.x, a.dy = x.data_ptr(), dy.data_ptr()
     a.zero = hipk.zero_page(x.device).data_ptr()
     a.taps = plan.fwd_taps.data_ptr()
     a.IH, a.IW, a.Cin = plan.ih, plan.iw, plan.cin
@@ -801,16 +832,58 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
     a.T, a.M, a.K = plan.T, M, plan.K
     a.cin_magic = plan.cin_magic
     a.colsum = 1 if colsum else 0
-    hipk.check(L.dtfa_conv_wgrad(C.byref(a), bmw, bnw, bkp, splits, hipk.stream()), "conv_wgrad")
-    if colsum:
-        if not direct:
-            hipk.check(L.dtfa_wgrad_reduce(slab.data_ptr(), splits, per_split, both.data_ptr(), None, 0, hipk.stream()),
+
+    def launch(cfg, dst=None, dst_both=None, acc=None):
+        """Slab kernel + reduction of one configuration ``(bmw, bnw, bkp, splits)`` into ``dst`` (default: the real
+        output; an autotuning run passes a scratch buffer so that repeated launches do not accumulate)."""
+        bmw, bnw, bkp, splits = cfg
+        dst = out if dst is None else dst
+        dst_both = (both if colsum else None) if dst_both is None else dst_both
+        acc = accumulate if acc is None else acc
+        # an unsplit reduction (few pixels: dense layers at small batch) writes the fp32 gradient in place
+        direct = splits == 1 and dst.dtype == torch.float32 and not acc
+        slab = (dst_both if colsum else dst) if direct else hipk.workspace(x.device, splits * per_split * 4)
+        a.slab = slab.data_ptr()
+        hipk.check(L.dtfa_conv_wgrad(C.byref(a), bmw, bnw, bkp, splits, hipk.stream()), "conv_wgrad")
+        if direct:
+            return
+        if colsum:
+            hipk.check(L.dtfa_wgrad_reduce(slab.data_ptr(), splits, per_split, dst_both.data_ptr(), None, 0, hipk.stream()),
                        "wgrad_reduce")
+            return
+        f32 = dst.data_ptr() if dst.dtype == torch.float32 else None
+        b16 = dst.data_ptr() if dst.dtype == torch.bfloat16 else None
+        hipk.check(L.dtfa_wgrad_reduce(slab.data_ptr(), splits, n, f32, b16, 1 if acc else 0, hipk.stream()),
+                   "wgrad_reduce")
+
+    rule = pick_wgrad_tile(M, plan.cout, plan.K, plan.cin)
+    cfg = rule
+    if tune.MODE != "off" and not _env_tile("DTFA_WGRAD_TILE"):
+        key = "%d,%d,%d,%d,%d,%d,%d" % (M, plan.cout, plan.K, plan.cin, plan.sy, plan.sx, colsum)
+        found = tune.lookup("wgrad", key)
+        if found is None and tune.measuring() and M * (plan.cout + plan.K) >= _TUNE_MIN_OUT:
+            scratch_both = torch.empty(per_split, dtype=torch.float32, device=x.device)
+            scratch = scratch_both[:n]
+            found = tune.measure("wgrad", key, _wgrad_candidates(M, plan.cout, plan.K),
+                                 lambda c: launch(c, scratch, scratch_both, False), rule)
+        if found is not None:
+            cfg = found
+    launch(cfg)
+    if colsum:
         return out, both[n:]
-    if direct:
-        return out
-    f32 = out.data_ptr() if out.dtype == torch.float32 else None
-    b16 = out.data_ptr() if out.dtype == torch.bfloat16 else None
-    hipk.check(L.dtfa_wgrad_reduce(slab.data_ptr(), splits, n, f32, b16, 1 if accumulate else 0, hipk.stream()),
-               "wgrad_reduce")
     return out
+
+
+def _wgrad_candidates(M: int, cout: int, K: int):
+    out = []
+    for (bmw, bnw, bkp), (per_cu, _) in _WGRAD_RESIDENT.items():
+        if (bmw >= 128 and cout <= bmw // 2) or (bnw >= 128 and K <= bnw // 2):
+            continue   # at least half of the tile would be padding
+        tiles = -(-cout // bmw) * -(-K // bnw)
+        kt_total = -(-M // bkp)
+        for r2 in (1, 2, 4, 6, 8):   # half rounds of resident workgroups
+            splits = max(1, min(256 * per_cu * r2 // (2 * tiles), max(1, kt_total // 8), 4096))
+            out.append((bmw, bnw, bkp, splits))
+    return sorted(set(out))
+
+
