@@ -158,7 +158,9 @@ _FWD_TILES = {(128, 192), (128, 128), (128, 64), (64, 64)}
 _BIG = os.environ.get("DTFA_CONV_BIG", "1") == "1"
 _BIG_MIN_BLOCKS = int(os.environ.get("DTFA_CONV_BIG_MIN_BLOCKS", "300"))
 # 256 x 128 macro tile (512-thread workgroups) for compute-bound layers.
-_WIDE = os.environ.get("DTFA_CONV_WIDE", "1") == "1"
+# (the 256 x 128 macro tile is a candidate of the measured table only: timed inside training steps at batch 256 .. 2048
+# it was the fastest choice in 1 of the 97 launches the rule below used to give it, 20 % behind on average)
+_WIDE = os.environ.get("DTFA_CONV_WIDE", "0") == "1"
 _WIDE_MIN_K = int(os.environ.get("DTFA_CONV_WIDE_MIN_K", "256"))
 _WIDE_MIN_TILES = int(os.environ.get("DTFA_CONV_WIDE_MIN_TILES", "1024"))
 _WIDE_BK = int(os.environ.get("DTFA_CONV_WIDE_BK", "32"))
@@ -193,6 +195,8 @@ def pick_fwd_tile(M: int, cout: int, K: int, dense: bool = True) -> Tuple[int, i
     # width: channel counts that are multiples of 192 (Inception: 192, 384) get the 192-wide tile, which
     # wastes no columns; otherwise 128, or 64 for narrow outputs
     bn = 192 if cout % 192 == 0 else (128 if cout > 64 else 64)
+    if bn == 192:
+        bk = 32   # two 80 KB stages of a 192-wide BK = 64 tile leave room for ONE workgroup per CU: never the fastest
     bm = 128
     tiles = -(-M // bm) * -(-cout // bn)
     if bn == 64 and tiles < 512:
@@ -389,9 +393,9 @@ def _igemm_candidates(M: int, cout: int, K: int):
     for bm, bn in ((128, 192), (128, 128), (128, 64), (64, 64)):
         if bn >= 128 and cout <= bn // 2:
             continue   # at least half of the tile's columns would be padding
-        out += [(bm, bn, 32, 3, 0), (bm, bn, 64, 2, 0)]
+        out += [(bm, bn, 32, 3, 0), (bm, bn, 64, 2, 0), (bm, bn, 32, 2, 0)]
     if cout > 64:
-        out += [(256, 128, 32, 3, 0), (256, 128, 32, 3, 1)]
+        out += [(256, 128, 32, 3, 0), (256, 128, 32, 3, 1), (256, 128, 64, 2, 0)]
     if cout > 128 and K >= 128:
         out += [(256, 256, 64, 2, 0), (256, 256, 64, 2, 1)]
     return out

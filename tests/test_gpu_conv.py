@@ -155,6 +155,8 @@ def test_tail_of_last_round_recut_into_small_tiles(case, monkeypatch):
     xb, wb = x.bfloat16().cuda(), w.bfloat16().cuda()
     plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
     M = B * plan.oh * plan.ow
+    monkeypatch.setattr(cv, "_WIDE", True)          # the rules may hand out the 256 x 128 macro tile (second case)
+    monkeypatch.setattr(cv.tune, "MODE", "off")     # ... and the rules, not a measured table, choose here
     tile = cv.pick_fwd_tile(M, Cout, plan.K, True)
     m_main, tail = cv.split_tail(M, Cout, plan.K, tile[0], tile[1], True)
     assert tail is not None and 0 < m_main < M, (tile, m_main, tail)
