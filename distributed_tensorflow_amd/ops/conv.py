@@ -156,7 +156,8 @@ _FWD_TILES = {(128, 192), (128, 128), (128, 64), (64, 64)}
 
 # 256 x 256 macro tile for wide, deep layers.
 _BIG = os.environ.get("DTFA_CONV_BIG", "1") == "1"
-_BIG_MIN_BLOCKS = int(os.environ.get("DTFA_CONV_BIG_MIN_BLOCKS", "300"))
+_BIG_MIN_BLOCKS = int(os.environ.get("DTFA_CONV_BIG_MIN_BLOCKS", "192"))
+_BIG_MIN_K = int(os.environ.get("DTFA_CONV_BIG_MIN_K", "768"))
 # 256 x 128 macro tile (512-thread workgroups) for compute-bound layers.
 # (the 256 x 128 macro tile is a candidate of the measured table only: timed inside training steps at batch 256 .. 2048
 # it was the fastest choice in 1 of the 97 launches the rule below used to give it, 20 % behind on average)
@@ -183,11 +184,13 @@ def pick_fwd_tile(M: int, cout: int, K: int, dense: bool = True) -> Tuple[int, i
     forced = _env_tile("DTFA_CONV_TILE")
     if forced:
         return tuple(forced) if len(forced) == 4 else tuple(forced) + (2,)  # type: ignore[return-value]
-    # 256 x 256 macro tile (512 threads, each wave 64 x 128, two 64 KB stages, one workgroup per CU): half the
-    # L2 -> LDS bytes per FLOP of the 256 x 128 tile, which is what bounds the wide deep layers (14x14 / 7x7
-    # stages: +5 .. 25 % at batch 1024).  Needs at least a workgroup per CU and a dense (unit output stride)
-    # launch; the strided data-gradient phases have too few taps each.
-    if _BIG and dense and cout % 256 == 0 and K >= 512 and -(-M // 256) * (cout // 256) >= _BIG_MIN_BLOCKS:
+    # 256 x 256 macro tile (512 threads, each wave 64 x 128, two 64 KB stages, one workgroup per CU): the fewest
+    # L2 -> LDS bytes per FLOP, which is what bounds the wide deep layers (14x14 / 7x7 stages: +5 .. 25 % at batch
+    # 1024).  Measured inside training steps (profiles/tuned_launches.md) it wins for every output wider than 128
+    # channels -- 160 .. 768, multiples of 256 or not, strided data-gradient phases included -- once the reduction
+    # is deep and there is about a workgroup per CU; layers with K <= 512 and the heavy residual / batch-norm-tap
+    # epilogues are faster on 128 x 128 x 32.
+    if _BIG and cout > 128 and K >= _BIG_MIN_K and -(-M // 256) * -(-cout // 256) >= _BIG_MIN_BLOCKS:
         return 256, 256, 64, 2
     # k-depth: deep reductions amortise the per-tile barrier with BK = 64 (two 32 KB stages, two workgroups per
     # CU); below K = 1024 three 16 KB stages (two k-tiles of loads in flight, three workgroups per CU) win.
