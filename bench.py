@@ -117,10 +117,23 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
     ips = batch * world * args.steps / dt
-    return {"value": round(ips, 2), "ms_per_step": round(dt / args.steps * 1e3, 3), "final_loss": round(float(loss.item()), 4),
+    final_loss = round(float(loss.item()), 4)
+    comm = engine.comm_stats()
+    if args.hip_graph:
+        # A captured step holds the communicator's kernels: release the graph here, with the device idle, and not
+        # whenever the garbage collector finds the closure cycle -- possibly after the process group is gone, which
+        # the communicator's watchdog thread answers with an abort.
+        step = None
+        sg.graph = None
+        sg = None
+        import gc
+        gc.collect()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+    return {"value": round(ips, 2), "ms_per_step": round(dt / args.steps * 1e3, 3), "final_loss": final_loss,
             "per_gpu_batch": batch, "global_batch": batch * world, "optimizer": opt,
             "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2**30, 2) if device.type == "cuda" else 0.0,
-            "comm": engine.comm_stats()}
+            "comm": comm}
 
 
 def main():
@@ -256,6 +269,10 @@ def main():
     done.set()
     report()
     if dist.is_initialized():
+        gc.collect()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+        dist.barrier()
         dist.destroy_process_group()
 
 
