@@ -293,6 +293,19 @@ class TrainingSession:
     def close(self):
         for h in self.hooks:
             h.end(self)
+        self.release_graph()
+
+    def release_graph(self):
+        """Drop the captured step with the device idle.  A graph that holds a communicator's kernels must not outlive
+        the process group (the communicator's watchdog thread aborts the process when it does)."""
+        if self._graph is not None:
+            self._graph.graph = None
+            self._graph = None
+            import gc
+
+            gc.collect()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
     def save_checkpoint(self, saver, directory, step, background: bool = False):
         drain = getattr(self.engine, "drain", None)

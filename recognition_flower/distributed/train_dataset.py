@@ -283,6 +283,7 @@ def run_worker(spec):
                 print("Worker %d: injected fault at step %d" % (task_index, step), flush=True)
                 os._exit(17)
     print("finished training (worker %d, %.1fs, global step %d)" % (task_index, time.time() - t0, step))
+    sess.release_graph()   # (before any communicator goes away: a captured step holds its kernels)
     if hasattr(engine, "close"):
         engine.close(shutdown_ps=FLAGS.shutdown_ps and is_chief)
     if hasattr(data, "close"):
