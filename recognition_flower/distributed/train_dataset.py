@@ -50,6 +50,7 @@ flags.DEFINE_integer("batch_size", 32, "Training batch size ")
 flags.DEFINE_float("learning_rate", 0.001, "Learning rate")
 # additions
 flags.DEFINE_string("mode", "async_ps", "async_ps | sync_dp | sharded_ps | async_ssp")
+flags.DEFINE_float("bn_decay", 0.0, "decay of the Inception trunk's batch-norm moving statistics (0 = slim's 0.9997)")
 flags.DEFINE_string("model", "auto", "inception_v3_head | inception_v3_finetune (the trunk is trained too) | flower_cnn | resnet50 | auto")
 flags.DEFINE_integer("image_size", 299, "Network input size.")
 flags.DEFINE_integer("staleness", -1, "Staleness bound (async_ps: -1 = unbounded; async_ssp: delay in steps).")
@@ -176,6 +177,12 @@ def run_worker(spec):
     else:
         kw = {"dropout_rate": FLAGS.head_dropout_rate} if model_name == "flower_cnn" else {}
     model = build_model(model_name, num_classes=n_classes, device=device, **kw)
+    if FLAGS.bn_decay > 0 and hasattr(model, "trunk"):
+        from distributed_tensorflow_amd.models.layers import ConvBnAct
+
+        for m in model.trunk.modules():
+            if isinstance(m, ConvBnAct):
+                m.momentum = 1.0 - FLAGS.bn_decay
 
     opt_name = FLAGS.optimizer.lower()
     opt_kwargs = {"momentum": FLAGS.momentum, "weight_decay": FLAGS.weight_decay} if opt_name == "momentum" else {}

@@ -50,6 +50,8 @@ flags.DEFINE_float("learning_rate", 0.001, "Initial learning rate of the exponen
 flags.DEFINE_float("head_dropout_rate", 0.5, "Drop probability of the head dropout (the reference feeds 0.5).")
 flags.DEFINE_string("trunk_bn", "batch", "Inception trunk batch-norm while training: batch (statistics of the batch, as the "
                     "reference's is_training=True) | moving (frozen moving statistics, folded into the convolutions).")
+flags.DEFINE_float("bn_decay", 0.0, "Decay of the Inception trunk's batch-norm moving statistics (0 = slim's 0.9997, which "
+                   "needs ~10k steps to leave the initial 0 / 1; a short run that is to be evaluated or served wants e.g. 0.9).")
 flags.DEFINE_string("device", "auto", "cuda | cpu | auto")
 flags.DEFINE_integer("max_steps", 0, "Stop after this many steps (0 = n_epochs * iterations per epoch).")
 flags.DEFINE_integer("seed", 42, "Random seed.")
@@ -106,6 +108,12 @@ def main(argv):
     else:
         kw = {"dropout_rate": FLAGS.head_dropout_rate} if model_name == "flower_cnn" else {}
     model = build_model(model_name, num_classes=len(flower_classes), device=device, **kw)
+    if FLAGS.bn_decay > 0 and hasattr(model, "trunk"):
+        from distributed_tensorflow_amd.models.layers import ConvBnAct
+
+        for m in model.trunk.modules():
+            if isinstance(m, ConvBnAct):
+                m.momentum = 1.0 - FLAGS.bn_decay
     engine = DataParallelEngine(model, mode="sync_dp", optimizer="adam",
                                 lr=exponential_decay(FLAGS.learning_rate, decay_steps=200, decay_rate=0.95))
     saver = Saver(model, engine)
@@ -178,6 +186,12 @@ def main(argv):
                 acc_sum, loss_sum, n = acc_sum + ev["accuracy"] * k, loss_sum + ev["loss"] * k, n + k
             held_out = {"accuracy": acc_sum / n, "loss": loss_sum / n}
             print("held-out set (%d images): accuracy %.4f loss %.4f" % (n, held_out["accuracy"], held_out["loss"]))
+            if hasattr(model, "trunk") and getattr(model, "trunk_bn", "") == "batch" and FLAGS.bn_decay <= 0 \
+                    and sess.global_step < 5000:
+                # the evaluation normalises with the moving statistics, the training step with the batch's
+                print("  (evaluated with moving statistics that %d steps at decay 0.9997 have barely moved from their "
+                      "initial 0 / 1, as in the reference, which never updates them at all: --bn_decay=0.9 tracks the "
+                      "batch statistics, --trunk_bn=moving trains on the moving ones)" % sess.global_step)
             from distributed_tensorflow_amd.io.events import EventWriter
 
             ew = EventWriter(os.path.join(FLAGS.summaries_dir + str(FLAGS.model_version), "eval"))
