@@ -17,7 +17,6 @@ honoured through explicit ``(top, bottom, left, right)`` pads.
 from __future__ import annotations
 
 import ctypes as C
-import math
 import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple

@@ -18,8 +18,6 @@ backend; the data path itself never touches ``torch.distributed``.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
-
 import torch
 import torch.distributed as dist
 
