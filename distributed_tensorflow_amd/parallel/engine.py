@@ -28,7 +28,9 @@ node the same roles map onto RCCL collectives over xGMI:
     reference's unbounded races.  Stale gradients narrow the stable step-size
     range, most of all under momentum (one step of delay with heavy-ball
     momentum ``mu``: ``lr * curvature < 1 - mu`` instead of ``< 2 (1 + mu)``),
-    so this mode wants a correspondingly smaller rate than ``sync_dp``.
+    so this mode wants a correspondingly smaller rate than ``sync_dp``.  (First-order delay compensation,
+    ``g + lambda g*g (w_now - w_then)``, was tried on the ResNet-50 benchmark step and does not widen that range:
+    with momentum 0.9 and the sync rate the loss diverges for every lambda in 0.5 .. 8, as without it.)
 
 Buckets are sized for the xGMI mesh: a ring collective moves ``bucket/N`` per
 link per step, so ``bucket_mb`` defaults to 32 MiB (4 MiB messages at N = 8)
