@@ -67,8 +67,14 @@
 // (WG * BM + BN) * BK operand bytes from L2 into LDS per WG * BM * BN * BK multiply-adds; that path (measured
 // ~12 TB/s chip-wide with ~90 % L2 hits) is what bounds the compute-heavy layers, and sharing the weight tile
 // takes a quarter of the bytes per FLOP away at 128 x 128.
-template <int BM, int BN, int BK, int EPI, int NST, int WG>
-__global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN > 128 * 128 ? 2 : (BM * BN <= 128 * 64 ? CONV_NARROW_OCC : 3)))) void conv_igemm_kernel(ConvArgs p) {
+//
+// KSP > 1 (with WG = 1) splits the REDUCTION over KSP groups of 2 x 2 waves inside one workgroup: a k-tile is
+// KSP * BK deep, group g stages and multiplies the slice [g * BK, (g + 1) * BK) of it for the same output tile, and
+// the groups' accumulators are summed through LDS before the epilogue.  A launch of few tiles with a deep reduction
+// (the 8x8 / 17x17 Inception layers at batch 32, single-image serving) is a chain of k-tiles on a mostly idle chip;
+// its pace is the fixed cost of a k-tile, so KSP times fewer of them is nearly KSP times faster.
+template <int BM, int BN, int BK, int EPI, int NST, int WG, int KSP = 1>
+__global__ __launch_bounds__(256 * WG * KSP, (KSP > 1 ? 1 : WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN > 128 * 128 ? 2 : (BM * BN <= 128 * 64 ? CONV_NARROW_OCC : 3)))) void conv_igemm_kernel(ConvArgs p) {
   constexpr int S = BK / 8;            // 16-byte slots per LDS row
   constexpr int ROWB = BK * 2;         // bytes per LDS row
   constexpr int RPI = 1024 / ROWB;     // rows covered by one wave-instruction
@@ -77,9 +83,12 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int KS = BK / 16;
-  constexpr int STAGE = (WG * BM + BN) * ROWB;   // [A of group 0][A of group 1][B]
+  static_assert(KSP == 1 || WG == 1, "the reduction is split over wave groups of a single-tile workgroup");
+  // WG = 2: [A of group 0][A of group 1][B];  KSP > 1: [A slice 0] .. [A slice KSP-1][B slice 0] .. [B slice KSP-1]
+  constexpr int STAGE = KSP > 1 ? KSP * (BM + BN) * ROWB : (WG * BM + BN) * ROWB;
   constexpr int NBW = NB / WG;                   // weight-tile loads per wave
   constexpr int EP = 4 * (BM / 2) * ((BN / 2) * 2 + 16) + 2 * (BN / 2) * 2 * 4;  // epilogue bytes per group
+  constexpr int BOFF = (KSP > 1 ? KSP : WG) * BM * ROWB;   // start of the weight rows inside a stage
   static_assert(NA >= 1 && NBW >= 1 && NB % WG == 0, "tile too small for this staging");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = WG == 1 ? 0 : wid_all >> 2;   // wave group
+  const int grp = (WG == 1 && KSP == 1) ? 0 : wid_all >> 2;   // wave group
   const int wid = wid_all & 3;    // wave inside its 2 x 2 group
   const int wr = wid >> 1, wc = wid & 1;
 
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
   const unsigned mgroups = ((p.tile_m_count > 0 ? (unsigned)p.tile_m_count : mtiles - p.tile_m_base) + WG - 1) / WG;
   const unsigned ntiles = (p.Cout + BN - 1) / BN;
   const unsigned bid = xcd_remap(blockIdx.x, mgroups * ntiles);
-  const unsigned tile_m = p.tile_m_base + (bid / ntiles) * WG + grp, tile_n = bid % ntiles;
+  const unsigned tile_m = p.tile_m_base + (bid / ntiles) * WG + (KSP > 1 ? 0 : grp), tile_n = bid % ntiles;
   const bool valid = tile_m < mtiles;   // the last macro tile may have a group without rows
   const int m0 = valid ? (int)(tile_m * BM) : p.M, n0 = tile_n * BN;
 
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
   bool bok[NBW];
 #pragma unroll
   for (int i = 0; i < NBW; ++i) {
-    int n = n0 + (i * 4 * WG + wid_all) * RPI + row_in_inst;
+    int n = n0 + (KSP > 1 ? (i * 4 + wid) : (i * 4 * WG + wid_all)) * RPI + row_in_inst;
     bok[i] = n < p.Cout;
     bbase[i] = p.w + (size_t)(bok[i] ? n : 0) * p.K;
   }
@@ -161,8 +170,8 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
   bool st_kvalid = false;
   auto stage_begin = [&](int kt, int buf) {
     st_sa = lds_tiles + buf * STAGE + grp * (BM * ROWB);
-    st_sb = lds_tiles + buf * STAGE + WG * BM * ROWB;
-    st_kc8 = kt * BK + cslot * 8;
+    st_sb = lds_tiles + buf * STAGE + BOFF + (KSP > 1 ? grp * (BN * ROWB) : 0);
+    st_kc8 = (KSP > 1 ? (kt * KSP + grp) * BK : kt * BK) + cslot * 8;
     st_kvalid = st_kc8 < p.K;
     if (!pointwise) {
       const int tap = (int)__umulhi((unsigned)st_kc8, p.cin_magic);
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
     } else {
       const int i = j - NA;
       const bf16* src = (st_kvalid && bok[i]) ? bbase[i] + st_kc8 : p.zero;
-      glds16(src, st_sb + (i * 4 * WG + wid_all) * 1024);
+      glds16(src, st_sb + (KSP > 1 ? (i * 4 + wid) : (i * 4 * WG + wid_all)) * 1024);
     }
   };
   auto stage = [&](int kt, int buf) {
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     int row = wc * WN + nt * 32 + (lane & 31);
-    boff[nt] = WG * BM * ROWB + row * ROWB;
+    boff[nt] = BOFF + (KSP > 1 ? grp * (BN * ROWB) : 0) + row * ROWB;
     bswz[nt] = swz_of_row<BK>(row);
   }
   const int khalf = lane >> 5;
@@ -223,10 +232,10 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
 
-  const int KT = (p.K + BK - 1) / BK;
+  const int KT = (p.K + KSP * BK - 1) / (KSP * BK);
   // epilogue operands of the first readback passes, requested ahead of the main loop (narrow tiles only: the
   // registers come on top of the accumulators)
-  constexpr bool PRE = WG == 1 && BN <= 128 && BK == 32 && EPI != 1;
+  constexpr bool PRE = WG == 1 && KSP == 1 && BN <= 128 && BK == 32 && EPI != 1;
   EpiPrefetch<BM, BN> pre;
   if (PRE && valid) epi_prefetch<BM, BN, EPI>(p, pre, wid, lane, m0, n0);
   constexpr int LPS = NA + NBW;  // LDS-DMA loads per thread and stage
@@ -421,15 +430,53 @@ __global__ __launch_bounds__(256 * WG, (WG == 2 ? (BN > 128 ? 1 : 2) : (BM * BN 
     return;
   }
 #endif
-  // each group stages its output through its own part of the (now idle) tile area
-  conv_epilogue<BM, BN, EPI, PRE>(p, acc, lds_tiles + grp * EP, wid, lane, m0, n0, tile_m, valid, &pre);
+  if (KSP > 1) {
+    // sum the groups' accumulators into group 0: group g parks its registers behind the epilogue areas (lane-major,
+    // one float4 per store), group 0 adds them, one group after the other
+    float* red = (float*)(lds_tiles + KSP * EP) + ((size_t)wid * 64 + lane) * (MT * NT * 16);
+#pragma unroll
+    for (int g = 1; g < KSP; ++g) {
+      if (grp == g) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *(f32x4*)(red + (mt * NT + nt) * 16 + q * 4) = f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1],
+                                                                  acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 v = *(const f32x4*)(red + (mt * NT + nt) * 16 + q * 4);
+              acc[mt][nt][4 * q] += v[0];
+              acc[mt][nt][4 * q + 1] += v[1];
+              acc[mt][nt][4 * q + 2] += v[2];
+              acc[mt][nt][4 * q + 3] += v[3];
+            }
+      }
+      __syncthreads();
+    }
+  }
+  // each group stages its output through its own part of the (now idle) tile area; with a split reduction only
+  // group 0 holds the tile, the others walk through the epilogue's barriers without rows
+  const bool has_tile = KSP == 1 || grp == 0;
+  conv_epilogue<BM, BN, EPI, PRE>(p, acc, lds_tiles + grp * EP, wid, lane, has_tile ? m0 : p.M, n0, tile_m,
+                                  valid && has_tile, &pre);
 }
 
-template <int BM, int BN, int BK, int EPI, int NST, int WG>
+template <int BM, int BN, int BK, int EPI, int NST, int WG, int KSP = 1>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   constexpr int ROWB = BK * 2;
-  constexpr int STAGE = (WG * BM + BN) * ROWB;
-  constexpr int EP = WG * (4 * (BM / 2) * ((BN / 2) * 2 + 16) + 2 * (BN / 2) * 2 * 4);  // row tiles + statistics exchange
+  constexpr int STAGE = KSP > 1 ? KSP * (BM + BN) * ROWB : (WG * BM + BN) * ROWB;
+  // row tiles + statistics exchange per group (+ the accumulator exchange of a split reduction)
+  constexpr int EP = WG * KSP * (4 * (BM / 2) * ((BN / 2) * 2 + 16) + 2 * (BN / 2) * 2 * 4) + (KSP > 1 ? BM * BN * 4 : 0);
   size_t lds = MAX_TAPS * 4 + (size_t)((NST * STAGE > EP) ? NST * STAGE : EP);
   unsigned mtiles = a.tile_m_count > 0 ? (unsigned)a.tile_m_count : (a.M + BM - 1) / BM - a.tile_m_base;
   unsigned ntiles = (a.Cout + BN - 1) / BN;
@@ -440,22 +487,22 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   (void)hipGetDevice(&dev);
   dev = (dev >= 0 && dev < 64) ? dev : 0;
   if (!attr_set[dev] && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, EPI, NST, WG>,
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, EPI, NST, WG, KSP>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, EPI, NST, WG>), dim3(mgroups * ntiles), dim3(256 * WG), lds,
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, EPI, NST, WG, KSP>), dim3(mgroups * ntiles), dim3(256 * WG * KSP), lds,
                      stream, a);
   return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int BK, int NST, int WG = 1>
+template <int BM, int BN, int BK, int NST, int WG = 1, int KSP = 1>
 static int launch_conv_epi(const ConvArgs& a, hipStream_t stream) {
-  if (a.bn_y != nullptr || a.bn_gate_store) return launch_conv<BM, BN, BK, 3, NST, WG>(a, stream);
-  if (a.stats != nullptr || a.stat_acc != nullptr) return launch_conv<BM, BN, BK, 1, NST, WG>(a, stream);
+  if (a.bn_y != nullptr || a.bn_gate_store) return launch_conv<BM, BN, BK, 3, NST, WG, KSP>(a, stream);
+  if (a.stats != nullptr || a.stat_acc != nullptr) return launch_conv<BM, BN, BK, 1, NST, WG, KSP>(a, stream);
   if (a.bias != nullptr || a.relu || a.oscale != nullptr || a.ldo != a.Cout)
-    return launch_conv<BM, BN, BK, 2, NST, WG>(a, stream);  // (omask rides on relu)
-  return launch_conv<BM, BN, BK, 0, NST, WG>(a, stream);
+    return launch_conv<BM, BN, BK, 2, NST, WG, KSP>(a, stream);  // (omask rides on relu)
+  return launch_conv<BM, BN, BK, 0, NST, WG, KSP>(a, stream);
 }
 
 // Number of partial-statistics rows the kernel writes for a given M and BM (one per row of tiles; a 256-row
@@ -465,7 +512,19 @@ extern "C" int dtfa_conv_stats_rows(int M, int bm) {
   return (M + bm - 1) / bm;
 }
 
+static int conv_igemm_dispatch(const ConvArgs* a, int bm, int bn, int bk, int nst, int ksp, hipStream_t stream);
+
 extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int nst, hipStream_t stream) {
+  return conv_igemm_dispatch(a, bm, bn, bk, nst, 1, stream);
+}
+
+// ``ksp`` > 1: the reduction of every tile split over ksp wave groups of one workgroup (the 64 x 64 x 64 tile with two
+// stages: 2 or 4 groups).
+extern "C" int dtfa_conv_igemm_ks(const ConvArgs* a, int bm, int bn, int bk, int nst, int ksp, hipStream_t stream) {
+  return conv_igemm_dispatch(a, bm, bn, bk, nst, ksp, stream);
+}
+
+static int conv_igemm_dispatch(const ConvArgs* a, int bm, int bn, int bk, int nst, int ksp, hipStream_t stream) {
   if (a->Cin % 8 != 0 || a->Cout % 8 != 0 || a->T > MAX_TAPS || a->T < 1) return -1;
   if ((a->x2 == nullptr && a->K != a->T * a->Cin) || a->K >= (1 << 16)) return -2;
   if ((long long)a->IH * a->IW >= (1ll << 24) || (long long)a->IH * a->IW * a->Cin >= (1ll << 32)) return -2;
@@ -503,6 +562,11 @@ extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int ns
         ((long long)a->tile_m_base + (a->tile_m_count > 0 ? a->tile_m_count - 1 : 0)) * unit >= a->M)
       return -9;
     if (a->tile_m_count > 0 && bm == 256 && (a->tile_m_count & 1)) return -9;   // whole macro tiles
+  }
+  if (ksp != 1) {
+    if (bm == 64 && bn == 64 && bk == 64 && nst == 2 && ksp == 2) return launch_conv_epi<64, 64, 64, 2, 1, 2>(*a, stream);
+    if (bm == 64 && bn == 64 && bk == 64 && nst == 2 && ksp == 4) return launch_conv_epi<64, 64, 64, 2, 1, 4>(*a, stream);
+    return -3;
   }
   // bm == 256: two wave groups of 128 rows sharing one weight tile
   if (bm == 256 && bn == 128 && bk == 32 && nst == 3) return launch_conv_epi<128, 128, 32, 3, 2>(*a, stream);

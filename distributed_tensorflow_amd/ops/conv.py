@@ -349,9 +349,10 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     want_part = stats or bn_tap is not None
 
     def launch(cfg):
-        """One configuration ``(bm, bn, bk, stages, tail)``: the main launch and, with ``tail``, the second launch
-        that re-cuts a partly filled last round (``split_tail``).  Returns the partial-statistics rows."""
-        bm, bn, bk, nst, use_tail = cfg
+        """One configuration ``(bm, bn, bk, stages, tail[, k-split])``: the main launch and, with ``tail``, the second
+        launch that re-cuts a partly filled last round (``split_tail``).  Returns the partial-statistics rows."""
+        bm, bn, bk, nst, use_tail = cfg[:5]
+        ksp = cfg[5] if len(cfg) > 5 else 1
         m_main, tail = (split_tail(M, cout, K, bm, bn, dense_out) if (use_tail and stat_acc is None) else (M, None))
         part = None
         if want_part:
@@ -360,8 +361,12 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
         a.stats = hipk.ptr(part)
         a.tile_m_base = a.stat_row_base = 0
         a.tile_m_count = m_main // (128 if bm == 256 else bm) if tail is not None else 0
-        hipk.check(L.dtfa_conv_igemm(C.byref(a), bm, bn, bk, nst, hipk.stream()),
-                   "conv_igemm %dx%dx%d/%d" % (bm, bn, bk, nst))
+        if ksp > 1:
+            hipk.check(L.dtfa_conv_igemm_ks(C.byref(a), bm, bn, bk, nst, ksp, hipk.stream()),
+                       "conv_igemm %dx%dx%d/%d k-split %d" % (bm, bn, bk, nst, ksp))
+        else:
+            hipk.check(L.dtfa_conv_igemm(C.byref(a), bm, bn, bk, nst, hipk.stream()),
+                       "conv_igemm %dx%dx%d/%d" % (bm, bn, bk, nst))
         if tail is not None:
             tbm, tbn, tbk, tnst = tail
             a.tile_m_count = 0
@@ -372,6 +377,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
         return part
 
     rule = pick_fwd_tile(M, cout, K, dense_out) + (1,)
+    rule += (pick_ksplit(rule, M, cout, K),)
     cfg = rule
     if tune.MODE != "off" and stat_acc is None and not _env_tile("DTFA_CONV_TILE"):
         # epilogue class as the kernel dispatches it: its cost differs per tile shape, so it is part of the key
@@ -381,9 +387,31 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
         found = tune.lookup("igemm", key)
         if found is None and tune.measuring() and M * cout >= _TUNE_MIN_OUT:
             found = tune.measure("igemm", key, _igemm_candidates(M, cout, K), launch, rule)
-        if found is not None:
-            cfg = found
+        if found is not None:   # entries measured before the reduction split existed carry no split: the rule adds it
+            cfg = found if len(found) > 5 else tuple(found) + (pick_ksplit(found, M, cout, K),)
     return launch(cfg)
+
+
+# Reduction split inside the workgroup (conv_igemm.hip, KSP): for launches of few tiles -- the small-launch path's
+# 64 x 64 x 64 tile -- with a deep reduction, 2 or 4 wave groups each take a slice of every k-tile.
+_KSPLIT = os.environ.get("DTFA_CONV_KSPLIT", "auto")
+_KSPLIT_MAX_TILES = int(os.environ.get("DTFA_CONV_KSPLIT_MAX_TILES", "512"))
+
+
+def pick_ksplit(tile, M: int, cout: int, K: int) -> int:
+    if tuple(tile[:4]) != (64, 64, 64, 2) or _KSPLIT == "0":
+        return 1
+    if _KSPLIT in ("2", "4"):
+        return int(_KSPLIT)
+    tiles = -(-M // 64) * -(-cout // 64)
+    if tiles > _KSPLIT_MAX_TILES:
+        return 1
+    # graph-timed at batch 32 (tools/dev/sweep_ksplit.py): up to a workgroup per CU, 8x8 2048->384 17.6 -> 12.5 (two
+    # groups) -> 11.7 us (four), 8x8 3x3 448->384 (K = 4032) 34.0 -> 22.7 -> 19.8; with 435 tiles (the 17x17 layers)
+    # two groups gain 10 % and four, at one 1024-thread workgroup per CU, lose 30 %
+    if tiles <= 256:
+        return 4 if K >= 1536 else (2 if K >= 512 else 1)
+    return 2 if K >= 768 else 1
 
 
 # configurations an autotuning run tries (tools/tune_conv.py); launches with less output than this keep the rules
@@ -400,6 +428,8 @@ def _igemm_candidates(M: int, cout: int, K: int):
         out += [(256, 128, 32, 3, 0), (256, 128, 32, 3, 1), (256, 128, 64, 2, 0)]
     if cout > 128 and K >= 128:
         out += [(256, 256, 64, 2, 0), (256, 256, 64, 2, 1)]
+    if K >= 256 and -(-M // 64) * -(-cout // 64) <= 2048:
+        out += [(64, 64, 64, 2, 0, 2), (64, 64, 64, 2, 0, 4)]
     return out
 
 

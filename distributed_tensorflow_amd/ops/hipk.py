@@ -91,6 +91,7 @@ def lib():
 
 class _Sigs:
     dtfa_conv_igemm = [C.POINTER(ConvArgs), c_int, c_int, c_int, c_int, c_void]
+    dtfa_conv_igemm_ks = [C.POINTER(ConvArgs), c_int, c_int, c_int, c_int, c_int, c_void]
     dtfa_conv_pro = [C.POINTER(ConvArgs), C.POINTER(ProArgs), c_int, c_int, c_int, c_void]
     dtfa_conv_stats_rows = [c_int, c_int]
     dtfa_dense_skinny = [C.POINTER(SkinnyArgs), c_void]

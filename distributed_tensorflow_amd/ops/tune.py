@@ -12,8 +12,9 @@ layers on the 192-wide tile with three stages).  This module keeps such measurem
   graph capture): each candidate runs once to warm up and ``REPS`` times between two events; the fastest is used
   for the rest of the process and can be written out with :func:`save`.  ``DTFA_AUTOTUNE=off`` ignores the table.
 
-All candidates compute the same bits of the convolution output (the reduction order over k does not depend on the
-tile); only the grouping of the batch-norm partial sums differs.
+All candidates without a reduction split compute the same bits of the convolution output (the reduction order over k
+does not depend on the tile); only the grouping of the batch-norm partial sums differs.  A sixth element 2 or 4 splits
+every k-tile over that many wave groups of the workgroup, which changes the fp32 summation order.
 """
 from __future__ import annotations
 

@@ -193,6 +193,58 @@ def test_tail_of_last_round_recut_into_small_tiles(case, monkeypatch):
     torch.testing.assert_close(y2[b0:b0 + 1].float().cpu(), want, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("ksp", ["2", "4"])
+@pytest.mark.parametrize("case", [(4, 8, 8, 448, 384, 3, 3, 1, 1, "SAME"), (2, 17, 17, 192, 160, 1, 7, 1, 1, "SAME"),
+                                  (1, 8, 8, 2048, 200, 1, 1, 1, 1, "VALID")])
+def test_reduction_split_inside_the_workgroup(case, ksp, monkeypatch):
+    """Launches of few tiles with a deep reduction split every k-tile over 2 or 4 wave groups of one workgroup and sum
+    the groups' accumulators through LDS: every epilogue (statistics rows, statistics by atomics, scale / bias / ReLU
+    into a channel slice, data gradient with addend and batch-norm sums) agrees with the unsplit launch up to the
+    rounding of a different summation order, and with the fp32 definition."""
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case, 21)
+    xb, wb = x.bfloat16().cuda(), w.bfloat16().cuda()
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    M = B * plan.oh * plan.ow
+    assert cv.pick_fwd_tile(M, Cout, plan.K, True) == (64, 64, 64, 2)
+    g = torch.Generator().manual_seed(22)
+    dy = torch.randn(B, plan.oh, plan.ow, Cout, generator=g).bfloat16().cuda()
+    addend = torch.randn(B, H, W, Cin, generator=g).bfloat16().cuda()
+    scale = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    shift = torch.randn(Cout, generator=g).cuda()
+
+    def run():
+        y, part = cv.conv_fwd(xb, wb, plan, want_stats=True)
+        acc = torch.zeros(2 * Cout, dtype=torch.float64, device="cuda")
+        y_acc, _ = cv.conv_fwd(xb, wb, plan, stat_acc=acc)
+        buf = torch.zeros(B, plan.oh, plan.ow, Cout + 16, dtype=torch.bfloat16, device="cuda")
+        cv.conv_fwd(xb, wb, plan, bias=shift, relu=True, scale=scale, out=buf[..., 8:8 + Cout])
+        tap = cv.BnBackwardTap()
+        gg = torch.Generator().manual_seed(23)
+        tap.y = torch.randn(B, H, W, Cin, generator=gg).bfloat16().cuda()
+        tap.mean = torch.randn(Cin, generator=gg).cuda() * 0.1
+        tap.invstd = (torch.rand(Cin, generator=gg) + 0.5).cuda()
+        tap.scale = (torch.rand(Cin, generator=gg) + 0.5).cuda()
+        tap.shift = torch.randn(Cin, generator=gg).cuda() * 0.2
+        tap.mask = None
+        tap.relu_mode = 2
+        dx = cv.conv_dgrad(dy, wb, plan, addend=addend, bn_tap=tap)
+        return y, part.double().sum(0), y_acc, acc.clone(), buf, dx, tap.partials.double().sum(0)
+
+    monkeypatch.setattr(cv.tune, "MODE", "off")
+    monkeypatch.setattr(cv, "_KSPLIT", "0")
+    ref_out = run()
+    monkeypatch.setattr(cv, "_KSPLIT", ksp)
+    got = run()
+    for a, b in zip(got, ref_out):
+        scale_ab = b.abs().max().item() + 1e-6
+        assert (a.double() - b.double()).abs().max().item() <= 1e-2 * scale_ab
+    assert torch.equal(got[0], got[2])                    # both statistics paths write the same convolution output
+    assert torch.equal(got[4][..., :8], torch.zeros_like(got[4][..., :8]))   # the slice's neighbours stay untouched
+    want = ref.conv2d(xb.float().cpu(), wb.float().cpu(), (sy, sx), pads)
+    torch.testing.assert_close(got[0].float().cpu(), want, rtol=2e-2, atol=2e-2)
+
+
 def test_dgrad_masked_addend():
     """The dgrad epilogue adds only the elements of ``addend`` whose bit is set."""
     case = (2, 14, 14, 64, 32, 1, 1, 1, 1, "VALID")
