@@ -103,8 +103,11 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
         def step():  # noqa: F811
             return sg.run(images, labels)[1]
 
-    for _ in range(args.warmup):
-        step()
+    first_loss = None
+    for i in range(args.warmup):
+        loss = step()
+        if i == 0:   # (read outside the timed region: shows next to final_loss whether the run descends)
+            first_loss = round(float(loss.item()), 4)
     sync()
     engine.reset_comm_stats()
     t0 = time.perf_counter()
@@ -131,6 +134,7 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
         if device.type == "cuda":
             torch.cuda.synchronize()
     return {"value": round(ips, 2), "ms_per_step": round(dt / args.steps * 1e3, 3), "final_loss": final_loss,
+            "first_loss": first_loss,
             "per_gpu_batch": batch, "global_batch": batch * world, "optimizer": opt,
             "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2**30, 2) if device.type == "cuda" else 0.0,
             "comm": comm}
@@ -220,6 +224,7 @@ def main():
             "dtype": "bf16" if device.type == "cuda" else "fp32 (cpu rehearsal)",
             "data": "synthetic",
             "final_loss": head["final_loss"],
+            "first_loss": head["first_loss"],
             "config": {"model": args.model, "global_batch": head["global_batch"], "per_gpu_batch": head["per_gpu_batch"],
                        "image_size": args.image_size or IMAGE_SIZE[args.model], "num_classes": 5, "parallelism": "dp%d" % world,
                        "mode": args.mode, "optimizer": head["optimizer"], "hip_graph": bool(args.hip_graph)},
@@ -251,7 +256,7 @@ def main():
             torch.cuda.empty_cache()
         try:
             r = run_config(args, args.also, args.also_batch or DEFAULT_BATCH[args.also], device, rank, world)
-            also[args.also] = {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "final_loss")}
+            also[args.also] = {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "first_loss", "final_loss")}
         except Exception as e:  # noqa: BLE001 -- the headline number stands on its own
             also[args.also] = {"error": "%s: %s" % (type(e).__name__, e)}
     # the headline model in the other two distribution modes (sharded parameter ownership: reduce-scatter +
@@ -263,7 +268,7 @@ def main():
         key = "%s/%s" % (args.model, other)
         try:
             r = run_config(args, args.model, head["per_gpu_batch"], device, rank, world, mode=other)
-            also[key] = {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "final_loss")}
+            also[key] = {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "first_loss", "final_loss")}
         except Exception as e:  # noqa: BLE001
             also[key] = {"error": "%s: %s" % (type(e).__name__, e)}
     done.set()

@@ -107,18 +107,21 @@ __global__ void jpeg_color_kernel(const unsigned char* __restrict__ planes, cons
   o[2] = (unsigned char)fminf(fmaxf(rintf(b), 0.f), 255.f);
 }
 
-static bool g_cos_ready = false;
+static bool g_cos_ready[64] = {};   // the cosine table is a per-device symbol
 
 extern "C" int dtfa_jpeg_decode_batch(const void* coefs, const void* descs, void* planes, void* out, int n_images,
                                       int max_blocks, int max_pixels, hipStream_t st) {
   if (n_images <= 0) return 0;
-  if (!g_cos_ready) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 63;
+  if (!g_cos_ready[dev]) {
     float h[8][8];
     for (int x = 0; x < 8; ++x)
       for (int u = 0; u < 8; ++u)
         h[x][u] = (u == 0 ? 0.35355339059327373f : 0.5f) * cosf((2 * x + 1) * u * 3.14159265358979323846f / 16.f);
     if (hipMemcpyToSymbol(HIP_SYMBOL(kCos), h, sizeof(h)) != hipSuccess) return -1;
-    g_cos_ready = true;
+    g_cos_ready[dev] = true;
   }
   hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_blocks + 63) / 64, n_images), dim3(64), 0, st, (const short*)coefs,
                      (const JpegDesc*)descs, (unsigned char*)planes);
