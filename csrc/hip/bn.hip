@@ -109,14 +109,12 @@ __device__ inline bool reduce_part_rows(const float* __restrict__ part, int R, i
 // Row-lane count of the finalize kernels: 8 lanes up to 64 partial rows, 32 lanes (1024 threads) above.
 static inline int finalize_lanes(int R) { return R <= 64 ? 8 : 32; }
 
-template <int RL>
-__global__ __launch_bounds__(32 * RL) void bn_finalize_kernel(
-    const float* __restrict__ part, int R, int C, float count, float eps, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-    float* __restrict__ shift, float* __restrict__ run_mean, float* __restrict__ run_var, float momentum) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  double s, ss;
-  if (!reduce_part_rows<RL>(part, R, C, c, s, ss)) return;
+// mean / invstd / scale / shift of one channel from its sums, running statistics updated in place
+__device__ inline void finalize_channel(int c, double s, double ss, float count, float eps,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                        float* __restrict__ shift, float* __restrict__ run_mean,
+                                        float* __restrict__ run_var, float momentum) {
   double mu = s / count;
   double var = ss / count - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -135,12 +133,97 @@ __global__ __launch_bounds__(32 * RL) void bn_finalize_kernel(
   }
 }
 
+template <int RL>
+__global__ __launch_bounds__(32 * RL) void bn_finalize_kernel(
+    const float* __restrict__ part, int R, int C, float count, float eps, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+    float* __restrict__ shift, float* __restrict__ run_mean, float* __restrict__ run_var, float momentum) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  double s, ss;
+  if (!reduce_part_rows<RL>(part, R, C, c, s, ss)) return;
+  finalize_channel(c, s, ss, count, eps, gamma, beta, mean, invstd, scale, shift, run_mean, run_var, momentum);
+}
+
+// Many partial rows (a layer of a few hundred row tiles sits between two convolutions of a dependent chain, and this
+// kernel is nothing but the latency of its loads): 16 channels x 256 row lanes per block, each thread four channels
+// per load and eight loads in flight, so 2048 rows are two trips to memory instead of sixteen.  The row lanes of a
+// wave are combined by shuffles, the 16 waves through LDS, both in a fixed order.  Needs C % 4 == 0.
+#ifndef BN_FINALIZE_WAVES
+#define BN_FINALIZE_WAVES 4
+#endif
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void bn_finalize_wide_kernel(
+    const float* __restrict__ part, int R, int C, float count, float eps, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+    float* __restrict__ shift, float* __restrict__ run_mean, float* __restrict__ run_var, float momentum) {
+  __shared__ double red[2][NW][16];   // [plane][wave][channel of the block]
+  constexpr int RL = 16 * NW;
+  const int q = threadIdx.x & 3, ty = threadIdx.x >> 2;
+  const int c4 = blockIdx.x * 16 + q * 4;
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c4 < C) {
+    int r = ty;
+    for (; r + 3 * RL < R; r += 4 * RL) {
+      f32x4 pv[4], qv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        pv[u] = *(const f32x4*)(part + ((size_t)(r + u * RL) * 2) * C + c4);
+        qv[u] = *(const f32x4*)(part + ((size_t)(r + u * RL) * 2 + 1) * C + c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s[i] += (double)pv[u][i];
+          ss[i] += (double)qv[u][i];
+        }
+    }
+    for (; r < R; r += RL) {
+      const f32x4 pv = *(const f32x4*)(part + ((size_t)r * 2) * C + c4);
+      const f32x4 qv = *(const f32x4*)(part + ((size_t)r * 2 + 1) * C + c4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s[i] += (double)pv[i];
+        ss[i] += (double)qv[i];
+      }
+    }
+  }
+  // lanes of a wave with the same channel quad differ in bits 2..5 of the lane number
+#pragma unroll
+  for (int off = 4; off < 64; off <<= 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[i] += __shfl_xor(s[i], off);
+      ss[i] += __shfl_xor(ss[i], off);
+    }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[0][wave][lane * 4 + i] = s[i];
+      red[1][wave][lane * 4 + i] = ss[i];
+    }
+  }
+  __syncthreads();
+  const int c = blockIdx.x * 16 + threadIdx.x;
+  if (threadIdx.x >= 16 || c >= C) return;
+  double ts = 0.0, tss = 0.0;
+  for (int w = 0; w < NW; ++w) {
+    ts += red[0][w][threadIdx.x];
+    tss += red[1][w][threadIdx.x];
+  }
+  finalize_channel(c, ts, tss, count, eps, gamma, beta, mean, invstd, scale, shift, run_mean, run_var, momentum);
+}
+
 extern "C" int dtfa_bn_finalize(const float* part, int R, int C, float count, float eps, const float* gamma,
                                 const float* beta, float* mean, float* invstd, float* scale, float* shift,
                                 float* run_mean, float* run_var, float momentum, hipStream_t st) {
   if (finalize_lanes(R) == 8)
     hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3((C + 31) / 32), dim3(256), 0, st, part, R, C, count, eps, gamma,
                        beta, mean, invstd, scale, shift, run_mean, run_var, momentum);
+  else if (C % 4 == 0 && ((size_t)part & 15) == 0)
+    hipLaunchKernelGGL(bn_finalize_wide_kernel<BN_FINALIZE_WAVES>, dim3((C + 15) / 16), dim3(64 * BN_FINALIZE_WAVES), 0, st, part, R, C, count, eps,
+                       gamma, beta, mean, invstd, scale, shift, run_mean, run_var, momentum);
   else
     hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3((C + 31) / 32), dim3(1024), 0, st, part, R, C, count, eps,
                        gamma, beta, mean, invstd, scale, shift, run_mean, run_var, momentum);

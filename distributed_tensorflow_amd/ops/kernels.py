@@ -26,15 +26,16 @@ def _as2d(t: torch.Tensor) -> Tuple[int, int]:
 
 # ------------------------------------------------------------------ batch norm
 _REDUCE_ROWS_PER_SPLIT = int(os.environ.get("DTFA_REDUCE_ROWS_PER_SPLIT", "16"))
+_DIRECT_ROWS = int(os.environ.get("DTFA_FINALIZE_DIRECT_ROWS", "2048"))
 
 
-def reduce_partials(part: torch.Tensor, max_rows: int = 1024, direct_rows: int = 2048) -> torch.Tensor:
+def reduce_partials(part: torch.Tensor, max_rows: int = 1024, direct_rows: int = 0) -> torch.Tensor:
     """[R][NV][C] -> [RS<=max_rows][NV][C] (fixed summation order).  Up to ``direct_rows`` rows are left
     alone: the finalize kernels sum that many themselves (32 row lanes), which saves a launch per layer.
     Above that each output row sums ~16 input rows, so the pass is wide (R/16 x NV*C threads) and short instead
     of a few long serial chains of dependent loads."""
     R, NV, Cc = part.shape
-    if R <= direct_rows:
+    if R <= (direct_rows or _DIRECT_ROWS):
         return part
     rs = min(max_rows, max(64, -(-R // _REDUCE_ROWS_PER_SPLIT)))
     out = torch.empty((rs, NV, Cc), dtype=F32, device=part.device)
