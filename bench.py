@@ -148,7 +148,8 @@ def main():
     ap.add_argument("--model", default="resnet50", choices=sorted(DEFAULT_BATCH))
     ap.add_argument("--mode", default="sync_dp", choices=["sync_dp", "sharded_ps", "async_ssp"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default depends on the model)")
-    ap.add_argument("--bucket_mb", type=float, default=32.0)
+    ap.add_argument("--bucket_mb", type=float, default=0.0,
+                    help="gradient bucket size in MiB (0: 32, or a quarter of the gradient for models under 64 MiB)")
     ap.add_argument("--staleness", type=int, default=1)
     ap.add_argument("--grad_dtype", default="fp32", choices=["fp32", "bf16"],
                     help="dtype of the gradient buckets (what the collectives move): bf16 halves the bytes on xGMI")

@@ -35,7 +35,8 @@ node the same roles map onto RCCL collectives over xGMI:
 Buckets are sized for the xGMI mesh: a ring collective moves ``bucket/N`` per
 link per step, so ``bucket_mb`` defaults to 32 MiB (4 MiB messages at N = 8)
 which keeps transfers bandwidth- rather than latency-bound while still giving
-ResNet-50 several buckets to overlap with backward.
+ResNet-50 several buckets to overlap with backward.  ``bucket_mb=0`` picks the size: 32 MiB for models with at
+least 64 MiB of gradient, a quarter of the gradient (at least 1 MiB) below that.
 
 The same code runs on CPU tensors with the ``gloo`` backend; that is how the
 multi-process tests exercise it.
@@ -73,6 +74,13 @@ class DataParallelEngine:
         self.collective = self.distributed and (self.world > 1 or os.environ.get("DTFA_FORCE_COLLECTIVES") == "1")
         self.staleness = max(0, int(staleness)) if mode == "async_ssp" else 0
         shard_multiple = self.world if mode == "sharded_ps" else 1
+        if bucket_mb <= 0:
+            # automatic: 32 MiB for models with at least two such buckets of gradient; a small model (the flower CNN
+            # has 8 MiB) is cut in four, so that all but the last quarter is reduced while backward still runs
+            # instead of one collective after it
+            esz = torch.empty((), dtype=grad_dtype).element_size()
+            total_mb = sum(p.numel() for p in model.parameters() if p.requires_grad) * esz / float(1 << 20)
+            bucket_mb = 32.0 if total_mb >= 64.0 else max(1.0, total_mb / 4.0)
         self.flat = FlatParams(model, bucket_mb=bucket_mb, shard_multiple=shard_multiple, grad_dtype=grad_dtype)
         self.flat.on_bucket_ready = self._on_bucket_ready
         self._handles: List = []

@@ -326,3 +326,21 @@ def test_launch_geometry_rules():
         whole = -(-tiles * splits // int(slots))
         # as many splits as fit into a whole number of rounds: one more split would start another round
         assert 1 <= whole <= 4 and 0 <= whole - rounds < tiles / slots, (cout, bmw, bnw, splits, rounds)
+
+
+def test_automatic_bucket_size_cuts_small_models_in_several_buckets():
+    """bucket_mb = 0: a model with less than 64 MiB of gradient gets buckets of a quarter of it (at least 1 MiB), so
+    most of its reduction overlaps with backward; an explicit size is taken as given."""
+    import torch.nn as nn
+    from distributed_tensorflow_amd.parallel.engine import DataParallelEngine
+
+    def make():
+        torch.manual_seed(0)
+        return nn.Sequential(*[nn.Linear(512, 512) for _ in range(8)])   # 8 x 1 MiB
+
+    auto = DataParallelEngine(make(), mode="sync_dp", optimizer="momentum", lr=0.1, bucket_mb=0)
+    one = DataParallelEngine(make(), mode="sync_dp", optimizer="momentum", lr=0.1, bucket_mb=32.0)
+    a, o = auto.comm_stats(), one.comm_stats()
+    assert o["buckets"] == 1 and a["buckets"] >= 4
+    assert max(a["bucket_bytes"]) <= 2.1 * (1 << 20) + 4 * 512 * 4
+    assert a["gradient_bytes"] == o["gradient_bytes"]
