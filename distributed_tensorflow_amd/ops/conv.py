@@ -133,6 +133,8 @@ class ConvPlan:
         self.cin_magic = _magic(cin)
         self.cout_magic = _magic(cout)
         self.is_pointwise = kh == 1 and kw == 1 and sy == 1 and sx == 1 and not any(self.pads)
+        # same-size 3x3: every tap of the forward and of the data-gradient launch lies within one pixel
+        self.near_taps = kh == 3 and kw == 3 and sy == 1 and sx == 1 and self.pads == (1, 1, 1, 1)
 
 
 _plans: Dict[tuple, ConvPlan] = {}
@@ -310,7 +312,7 @@ STREAM_OUT_BYTES = int(os.environ.get("DTFA_CONV_STREAM_OUT_BYTES", str(256 << 2
 def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, osx, oy0, ox0, isy, isx, B,
                   cin_magic, bias=None, relu=False, stats=False, addend=None, zero_taps=False, addend_mask=None,
                   bn_tap=None, oscale=None, ldo=0, omask=None, dbias=None, x2=None, addend_shift=(0, 0),
-                  stat_acc=None):
+                  stat_acc=None, near_taps=False):
     M = B * oyn * oxn
     K = T * cin + (x2.shape[-1] if x2 is not None else 0)
     dense_out = osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow
@@ -361,7 +363,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
         a.stats = hipk.ptr(part)
         a.tile_m_base = a.stat_row_base = 0
         a.tile_m_count = m_main // (128 if bm == 256 else bm) if tail is not None else 0
-        if ksp > 1:
+        if ksp != 1:
             hipk.check(L.dtfa_conv_igemm_ks(C.byref(a), bm, bn, bk, nst, ksp, hipk.stream()),
                        "conv_igemm %dx%dx%d/%d k-split %d" % (bm, bn, bk, nst, ksp))
         else:
@@ -389,11 +391,18 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
             found = tune.measure("igemm", key, _igemm_candidates(M, cout, K), launch, rule)
         if found is not None:   # entries measured before the reduction split existed carry no split: the rule adds it
             cfg = found if len(found) > 5 else tuple(found) + (pick_ksplit(found, M, cout, K),)
+    if (_HALO and near_taps and cin == 64 and cout <= 64 and x2 is None and dense_out and iw <= 160
+            and M >= _HALO_MIN_ROWS and not _env_tile("DTFA_CONV_TILE")):
+        cfg = (128, 64, 64, 3, 0, -1)   # conv_halo_kernel: the pixel operand staged once per tile, not once per tap
     return launch(cfg)
 
 
 # Reduction split inside the workgroup (conv_igemm.hip, KSP): for launches of few tiles -- the small-launch path's
 # 64 x 64 x 64 tile -- with a deep reduction, 2 or 4 wave groups each take a slice of every k-tile.
+# conv_halo_kernel (same-size 3x3 over 64 channels with the pixel operand staged once per tile): bit-exact with the
+# ordinary kernel and no faster on the layers it was written for (profiles/conv_pmc.md, last section): off
+_HALO = os.environ.get("DTFA_CONV_HALO", "0") == "1"
+_HALO_MIN_ROWS = int(os.environ.get("DTFA_CONV_HALO_MIN_ROWS", str(1 << 16)))
 _KSPLIT = os.environ.get("DTFA_CONV_KSPLIT", "auto")
 _KSPLIT_MAX_TILES = int(os.environ.get("DTFA_CONV_KSPLIT_MAX_TILES", "512"))
 
@@ -507,7 +516,7 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
     part = _launch_igemm(x, w, y, plan.fwd_taps, plan.T, plan.ih, plan.iw, plan.cin, plan.oh, plan.ow, plan.cout,
                          plan.oh, plan.ow, 1, 1, 0, 0, plan.sy, plan.sx, B, plan.cin_magic, bias, relu, want_stats,
                          addend=residual, zero_taps=plan.is_pointwise, oscale=scale, ldo=ldo, omask=mask_out, x2=x2,
-                         stat_acc=stat_acc)
+                         stat_acc=stat_acc, near_taps=plan.near_taps)
     return y, part
 
 
@@ -808,7 +817,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, plan: ConvPlan, addend: Option
         part = _launch_igemm(dy, wp, dx, ph.taps, ph.T, plan.oh, plan.ow, plan.cout, plan.ih, plan.iw, plan.cin,
                              ph.OYn, ph.OXn, plan.sy, plan.sx, ph.oy0, ph.ox0, 1, 1, B, plan.cout_magic,
                              addend=addend, zero_taps=plan.is_pointwise, addend_mask=addend_mask, bn_tap=bn_tap,
-                             x2=x2, dbias=dbias,
+                             x2=x2, dbias=dbias, near_taps=plan.near_taps,
                              addend_shift=(addend_stride[0].bit_length() - 1, addend_stride[1].bit_length() - 1)
                              if addend is not None else (0, 0))
         parts.append(part)

@@ -245,6 +245,57 @@ def test_reduction_split_inside_the_workgroup(case, ksp, monkeypatch):
     torch.testing.assert_close(got[0].float().cpu(), want, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("case", [(2, 56, 56, 64, 64), (3, 20, 12, 64, 32), (1, 9, 160, 64, 48), (2, 7, 5, 64, 64)])
+def test_same_size_3x3_with_the_pixel_operand_staged_once(case, monkeypatch):
+    """conv_halo_kernel (3x3, stride 1, 64 input channels: the pixels a tile touches over all nine taps brought into
+    LDS once, taps read at row offsets, out-of-image taps from a zero row) gives the bits of the ordinary kernel --
+    the reduction order is the same -- for the forward with statistics, the folded scale / bias / ReLU epilogue and
+    the data gradient with addend and batch-norm sums."""
+    B, H, W, Cin, Cout = case
+    full = (B, H, W, Cin, Cout, 3, 3, 1, 1, "SAME")
+    x, w, pads = _mk(full, 31)
+    xb, wb = x.bfloat16().cuda(), w.bfloat16().cuda()
+    plan = cv.get_plan(H, W, Cin, Cout, 3, 3, 1, 1, pads, "cuda")
+    assert plan.near_taps
+    g = torch.Generator().manual_seed(32)
+    dy = torch.randn(B, H, W, 64, generator=g).bfloat16().cuda()
+    wd = (torch.randn(64, 3, 3, Cout, generator=g) * 0.05).bfloat16().cuda()    # a layer Cout -> 64: its dgrad reads 64
+    dplan = cv.get_plan(H, W, Cout, 64, 3, 3, 1, 1, pads, "cuda")
+    addend = torch.randn(B, H, W, Cout, generator=g).bfloat16().cuda()
+    scale = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    shift = torch.randn(Cout, generator=g).cuda()
+
+    def run():
+        y, part = cv.conv_fwd(xb, wb, plan, want_stats=True)
+        z, _ = cv.conv_fwd(xb, wb, plan, bias=shift, relu=True, scale=scale)
+        tap = cv.BnBackwardTap()
+        gg = torch.Generator().manual_seed(33)
+        tap.y = torch.randn(B, H, W, Cout, generator=gg).bfloat16().cuda()
+        tap.mean = torch.randn(Cout, generator=gg).cuda() * 0.1
+        tap.invstd = (torch.rand(Cout, generator=gg) + 0.5).cuda()
+        tap.scale = (torch.rand(Cout, generator=gg) + 0.5).cuda()
+        tap.shift = torch.randn(Cout, generator=gg).cuda() * 0.2
+        tap.mask = None
+        tap.relu_mode = 2
+        dx = cv.conv_dgrad(dy, wd, dplan, addend=addend, bn_tap=tap)
+        return y, part, z, dx, tap.partials
+
+    monkeypatch.setattr(cv.tune, "MODE", "off")
+    monkeypatch.setattr(cv, "_HALO_MIN_ROWS", 0)
+    monkeypatch.setattr(cv, "_HALO", False)
+    want = run()
+    monkeypatch.setattr(cv, "_HALO", True)
+    got = run()
+    assert cv.pick_fwd_tile(B * H * W, Cout, 576, True)[0] in (64, 128)
+    for a, b in zip(got, want):
+        if a.dtype == torch.bfloat16:
+            assert torch.equal(a, b)
+        else:   # partial rows: one per 128-row tile here, per tile of the rule's choice there
+            torch.testing.assert_close(a.double().sum(0), b.double().sum(0), rtol=1e-5, atol=1e-3)
+    ref_y = ref.conv2d(xb.float().cpu(), wb.float().cpu(), (1, 1), pads)
+    torch.testing.assert_close(got[0].float().cpu(), ref_y, rtol=2e-2, atol=2e-2)
+
+
 def test_dgrad_masked_addend():
     """The dgrad epilogue adds only the elements of ``addend`` whose bit is set."""
     case = (2, 14, 14, 64, 32, 1, 1, 1, 1, "VALID")
