@@ -24,7 +24,10 @@ from __future__ import annotations
 
 from typing import Callable, Optional, Tuple
 
+import time
+
 import torch
+import torch.distributed as dist
 
 from ..ops import kernels as K
 
@@ -46,6 +49,14 @@ class StepGraph:
     def _capture(self, loss_fn) -> None:
         eng = self.engine
         torch.cuda.synchronize()
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            # The communicator's watchdog thread retires finished collectives by polling their events every 100 ms.
+            # A collective of the eager steps before this capture that it has not looked at yet would be polled
+            # DURING the capture, once the communicator's stream has joined it -- and HIP refuses a query of an
+            # event whose stream is capturing ("operation not permitted on an event last recorded in a capturing
+            # stream"), which the watchdog turns into an abort of the process (seen as an intermittent SIGABRT of
+            # captured sync_dp / sharded_ps runs).  The device is idle here, so a few watchdog periods empty its list.
+            time.sleep(0.35)
         eng.prepare_step()
         # Other threads keep issuing HIP calls while the capture runs -- RCCL's watchdog polls events of earlier
         # work, the input pipeline's helper thread uploads the next batch on its copy stream -- and

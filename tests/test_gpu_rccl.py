@@ -22,6 +22,21 @@ def _port():
     return str(p)
 
 
+def _failure_text(out: str) -> str:
+    """The lines of a failed child's output that name the failure (a watchdog abort prints its reason far above the
+    launcher's traceback), then its tail."""
+    try:   # the whole output next to the other run artefacts, when there is such a directory
+        d = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(d):
+            with open(os.path.join(d, "rccl_child_failure.log"), "w") as f:
+                f.write(out)
+    except OSError:
+        pass
+    keys = ("terminated with exception", "HIP error", "NCCL error", "RuntimeError", "Error:", "what():")
+    named = [l for l in out.splitlines() if any(k in l for k in keys)]
+    return "\n".join(named[:20]) + "\n...\n" + out[-1500:]
+
+
 @pytest.mark.parametrize("extra", [
     ["--mode", "sync_dp"],
     ["--mode", "sharded_ps"],
@@ -38,7 +53,7 @@ def test_bench_under_torchrun_one_rank(extra):
            "127.0.0.1", "--master-port", _port(), "bench.py", "--gpus", "1", "--model", "flower_cnn", "--batch", "32",
            "--steps", "4", "--warmup", "2"] + extra
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
-    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.returncode == 0, _failure_text(r.stdout)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["final_loss"] == out["final_loss"]  # finite
@@ -64,7 +79,7 @@ def test_resnet50_bench_under_torchrun_one_rank(extra):
            "127.0.0.1", "--master-port", _port(), "bench.py", "--gpus", "1", "--model", "resnet50", "--batch", "16",
            "--steps", "3", "--warmup", "2", "--also", "", "--also_modes", ""] + extra
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
-    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.returncode == 0, _failure_text(r.stdout)
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["config"]["model"] == "resnet50" and out["value"] > 0 and out["final_loss"] < 5.0
     assert out["comm"]["collective"] is True and out["comm"]["buckets"] >= 1
