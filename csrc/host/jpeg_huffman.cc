@@ -25,6 +25,21 @@ struct Huff {
   int mincode[17], maxcode[18], valptr[17];
   // 9-bit fast path: (length << 8) | value, 0 = not resolvable in 9 bits
   uint16_t fast[512];
+  // AC tables: code AND coefficient bits inside the 9-bit window: (coefficient << 8) | (run << 4) | total bits, 0 = no
+  int16_t fast_ac[512];
+  void build_fast_ac() {
+    for (int i = 0; i < 512; ++i) {
+      fast_ac[i] = 0;
+      const int f = fast[i];
+      if (!f) continue;
+      const int rs = f & 0xff, len = f >> 8;
+      const int run = rs >> 4, mag = rs & 15;
+      if (mag == 0 || len + mag > 9) continue;
+      int k = ((i << len) & 511) >> (9 - mag);   // the mag bits behind the code
+      if (k < (1 << (mag - 1))) k += (int)(~0u << mag) + 1;
+      if (k >= -128 && k <= 127) fast_ac[i] = (int16_t)(k * 256 + run * 16 + len + mag);
+    }
+  }
   // False for a code-length histogram that is not a prefix code (more codes of some length than that length has
   // left: Kraft sum > 1).  Such a table would index ``fast`` past its end.
   bool build(const uint8_t* bits, const uint8_t* v, int nvals) {
@@ -47,6 +62,7 @@ struct Huff {
       code <<= 1;
     }
     maxcode[17] = 0x7fffffff;
+    build_fast_ac();
     present = true;
     return true;
   }
@@ -60,6 +76,23 @@ struct BitReader {
   bool hit_marker = false;
   int pad_bytes = 0;  // zero bytes fed after the end of the entropy-coded data
   void fill() {
+    // common case: the next eight bytes hold no 0xff (no stuffing, no marker): append as many whole bytes as fit at once
+    if (!hit_marker && p + 8 <= end && cnt <= 56) {
+      uint64_t w;
+      memcpy(&w, p, 8);
+      w = __builtin_bswap64(w);
+      const uint64_t x = ~w;   // a 0xff byte of w is a zero byte of x
+      if (!((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull)) {
+        const int nbytes = (64 - cnt) >> 3;
+        const int nbits = nbytes * 8;
+        uint64_t add = w >> cnt;                              // first new byte right behind the cnt valid bits
+        if (cnt + nbits < 64) add &= ~0ull << (64 - cnt - nbits);   // drop the partial byte behind the whole ones
+        buf |= add;
+        cnt += nbits;
+        p += nbytes;
+        return;
+      }
+    }
     while (cnt <= 56) {
       uint8_t b = 0;
       if (hit_marker || p >= end) ++pad_bytes;
@@ -97,7 +130,8 @@ struct BitReader {
   }
 };
 
-inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+// value of an s-bit coefficient field (s >= 1): fields with a leading 0 bit are the negative half
+inline int extend(int v, int s) { return v + (((v >> (s - 1)) - 1) & (int)((~0u << s) + 1)); }
 
 inline int decode_symbol(BitReader& br, const Huff& h) {
   if (br.cnt < 16) br.fill();
@@ -306,16 +340,38 @@ int dtfa_jpeg_decode_coefs(const uint8_t* data, uint64_t n, DtfaJpegInfo* info, 
             pred[c] += diff;
             blk[0] = (int16_t)pred[c];
             for (int k = 1; k < 64;) {
-              int rs = decode_symbol(br, ha);
-              if (rs < 0) return -1;
-              int r = rs >> 4, sz = rs & 15;
+              // 32 bits in the window cover the longest code (16) and the longest coefficient (15) without a refill
+              if (br.cnt < 32) br.fill();
+              const int w9 = br.peek(9);
+              const int fa = ha.fast_ac[w9];
+              if (fa) {   // run, size and the coefficient itself from one lookup
+                k += (fa >> 4) & 15;
+                if (k > 63) return -1;
+                br.skip(fa & 15);
+                blk[kZigzag[k]] = (int16_t)(fa >> 8);
+                ++k;
+                continue;
+              }
+              int rs;
+              const int f = ha.fast[w9];
+              if (f) {
+                br.skip(f >> 8);
+                rs = f & 0xff;
+              } else {
+                rs = decode_symbol(br, ha);
+                if (rs < 0) return -1;
+              }
+              const int r = rs >> 4, sz = rs & 15;
               if (sz == 0) {
                 if (r == 15) { k += 16; continue; }
                 break;
               }
               k += r;
               if (k > 63) return -1;
-              blk[kZigzag[k]] = (int16_t)extend(br.get(sz), sz);
+              if (br.cnt < sz) br.fill();
+              const int v = br.peek(sz);
+              br.skip(sz);
+              blk[kZigzag[k]] = (int16_t)extend(v, sz);
               ++k;
             }
           }
