@@ -110,3 +110,11 @@ def rendezvous_from_cluster(spec: ClusterSpec) -> Dict[str, str]:
     return {"MASTER_ADDR": "127.0.0.1" if host in ("localhost", "") else host,
             "MASTER_PORT": str(int(port) + 1000),
             "RANK": str(spec.trainer_index), "WORLD_SIZE": str(len(spec.trainer_hosts))}
+
+
+def local_device_index(task_index: int, n_devices: int):
+    """GPU of trainer ``task_index`` when several TF_CONFIG workers share a machine with ``n_devices`` visible GPUs
+    (round-robin), or None when there is at most one device to choose from."""
+    if n_devices <= 1:
+        return None
+    return int(task_index) % int(n_devices)

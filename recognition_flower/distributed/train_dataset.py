@@ -166,6 +166,16 @@ def run_worker(spec):
         if device.type == "cuda":
             torch.cuda.set_device(tr[2])
             device = torch.device("cuda", tr[2])
+    elif spec.task_type is not None and device.type == "cuda" and device.index is None and world > 1:
+        # TF_CONFIG roles on one machine (run.sh, a TFJob pod with several GPUs): worker i takes GPU i modulo the
+        # number of visible devices, as the reference's one-worker-per-GPU deployments do with CUDA_VISIBLE_DEVICES;
+        # --device=cuda:N pins a device instead.  (Counting devices does not initialise the GPU.)
+        from distributed_tensorflow_amd.utils.cluster import local_device_index
+
+        idx = local_device_index(task_index, torch.cuda.device_count())
+        if idx is not None:
+            torch.cuda.set_device(idx)
+            device = torch.device("cuda", idx)
     is_chief = task_index == 0
     torch.manual_seed(1234)  # identical initial values on every worker
     model_name = _model_name(device)

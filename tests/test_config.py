@@ -123,3 +123,12 @@ def test_tfjob_style_cluster_with_chief_replica():
                                         "task": {"type": "worker", "index": 0}}))
     assert plain.is_chief and plain.trainer_index == 0 and plain.num_workers == 2
     assert rendezvous_from_cluster(plain)["MASTER_PORT"] == "1001"
+
+
+def test_tf_config_workers_spread_over_the_visible_gpus():
+    """Several TF_CONFIG workers on one machine: worker i trains on GPU i modulo the device count; with one (or no)
+    visible device there is nothing to choose."""
+    from distributed_tensorflow_amd.utils.cluster import local_device_index
+
+    assert [local_device_index(i, 8) for i in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
+    assert local_device_index(3, 1) is None and local_device_index(3, 0) is None

@@ -150,3 +150,28 @@ def test_model_server_on_gpu_matches_servable(tmp_path):
         assert server.batcher.stats()["batches"] == 3  # 10 images in chunks of max_batch = 4
     finally:
         server.stop()
+
+@pytest.mark.gpu
+def test_xgmi_parameter_server_via_tf_config_roles(tmp_path):
+    """The reference's launch (TF_CONFIG roles: one ps task, two workers; run.sh) with --ps_backend=xgmi: the ps task
+    has nothing to serve and exits, the workers own the variables in GPU memory and exchange gradients and values
+    through peer-mapped mailboxes (here both on the one GPU of the box), the chief writes the checkpoint."""
+    import socket
+
+    def port():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+    cluster = {"ps": ["localhost:%d" % port()], "worker": ["localhost:%d" % port(), "localhost:%d" % port()]}
+    common = ["train_dataset.py", "--synthetic", "--model=flower_cnn", "--image_size=64", "--batch_size=8",
+              "--train_steps=12", "--mode=async_ps", "--ps_backend=xgmi", "--staleness=1", "--device=cuda",
+              "--checkpoint_dir=%s/ckpt/" % tmp_path, "--summaries_dir=%s/events/" % tmp_path]
+    procs = []
+    for task in ({"type": "ps", "index": 0}, {"type": "worker", "index": 0}, {"type": "worker", "index": 1}):
+        env = dict(os.environ, TF_CONFIG=json.dumps({"cluster": cluster, "task": task}), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable] + common, cwd=DIST, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0, 0], outs
+    assert "nothing to serve" in outs[0]
+    assert "finished training (worker 0" in outs[1] and "finished training (worker 1" in outs[2]
+    assert int(bundle.read_bundle(bundle.latest_checkpoint(str(tmp_path / "ckpt")))["global_step"]) >= 12
