@@ -2,14 +2,21 @@
 """Headline benchmark: training throughput (images/sec, whole job) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--model resnet50|flower_cnn|inception_v3_head|inception_v3_finetune]
-                    [--mode sync_dp|sharded_ps|async_ssp] [--batch PER_GPU_BATCH]
+                    [--mode sync_dp|sharded_ps|async_ssp|async_ps] [--batch PER_GPU_BATCH]
 
-For N > 1 launch one rank per GPU with ``python -m torch.distributed.run`` (RANK /
-LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the environment); collectives
-run over RCCL.  Every timed step is a complete training step: forward,
-backward, gradient collective, fused optimizer update.  Data is synthetic
-(5-class flower_photos-shaped images, random-init weights); compute dtype is
-bf16 with fp32 master weights and fp32 accumulation.  Rank 0 prints one JSON
+One command starts the whole job: with ``--gpus N`` (N > 1) and no ``RANK`` / ``WORLD_SIZE`` in the environment this
+process only launches N rank processes (one per GPU, ``LOCAL_RANK`` = GPU index, rendezvous on a free port of
+127.0.0.1), relays rank 0's JSON line and exits with the first non-zero status of any rank.  The launcher never
+imports torch and never touches a GPU.  Started under ``python -m torch.distributed.run`` instead, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* are taken from the environment.  (The reference starts its job from one command
+as well: recognition_flower/distributed/run.sh:3-6.)
+
+Every timed step is a complete training step: forward, backward, gradient communication, fused optimizer update.
+``--mode`` selects how the ranks exchange gradients: RCCL all-reduce (``sync_dp``), reduce-scatter + owner update +
+all-gather (``sharded_ps``), delayed all-reduce (``async_ssp``) or the GPU-resident asynchronous parameter server
+with one-sided pushes and pulls over xGMI (``async_ps``: the reference's ps/worker scheme,
+recognition_flower/distributed/train_dataset.py:141-165).  Data is synthetic (5-class flower_photos-shaped images,
+random-init weights); compute dtype is bf16 with fp32 master weights and fp32 accumulation.  Rank 0 prints one JSON
 line.
 """
 from __future__ import annotations
@@ -21,24 +28,154 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-import torch
-import torch.distributed as dist
-
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-
-from distributed_tensorflow_amd.models import build_model  # noqa: E402
-from distributed_tensorflow_amd.ops import functional as F  # noqa: E402
-from distributed_tensorflow_amd.parallel.engine import DataParallelEngine  # noqa: E402
 
 # per-GPU batches sized for 288 GB of HBM: ResNet-50 at 1024 holds ~40 GB of activations and runs ~13 % more
 # images/s than at 256 (fixed per-layer costs and tile-quantisation tails amortise)
 DEFAULT_BATCH = {"resnet50": 2048, "flower_cnn": 1024, "inception_v3_head": 256, "inception_v3_finetune": 512}
 IMAGE_SIZE = {"resnet50": 224, "flower_cnn": 224, "inception_v3_head": 299, "inception_v3_finetune": 299}
+MODES = ("sync_dp", "sharded_ps", "async_ssp", "async_ps")
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="resnet50", choices=sorted(DEFAULT_BATCH))
+    ap.add_argument("--mode", default="sync_dp", choices=list(MODES))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default depends on the model)")
+    ap.add_argument("--bucket_mb", type=float, default=0.0,
+                    help="gradient bucket size in MiB (0: 32, or a quarter of the gradient for models under 64 MiB)")
+    ap.add_argument("--staleness", type=int, default=1,
+                    help="async_ssp: delay in steps; async_ps: how far a worker may run ahead (-1 = unbounded, 0 = lock step)")
+    ap.add_argument("--ps_apply", default="auto", choices=["auto", "per_push", "aggregate"],
+                    help="async_ps: one optimizer step per arrived gradient (the reference's ps) or one per lock-step round")
+    ap.add_argument("--ps_timeout", type=float, default=30.0,
+                    help="async_ps: seconds after which a silent peer stops counting")
+    ap.add_argument("--grad_dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="dtype of the gradient buckets (what the collectives move): bf16 halves the bytes on xGMI")
+    ap.add_argument("--p2p_kb", type=int, default=0,
+                    help="gradient buckets up to this many KiB use the one-shot xGMI mailbox all-reduce (sync_dp)")
+    ap.add_argument("--trunk_bn", default="batch", choices=["batch", "moving"],
+                    help="inception_v3_head: trunk batch-norm on batch statistics (reference) or frozen moving statistics")
+    ap.add_argument("--also", default="flower_cnn",
+                    help="second model measured after the headline one and reported under \"also\" ('' = none)")
+    ap.add_argument("--also_batch", type=int, default=0, help="per-GPU batch of the second model (default: its own)")
+    ap.add_argument("--also_modes", default="sharded_ps,async_ssp,async_ps",
+                    help="distribution modes the headline model is measured in as well, reported under \"also\" ('' = none)")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu: rehearse the multi-rank control flow over gloo (not a measurement)")
+    ap.add_argument("--image_size", type=int, default=0, help="square image size (default: the model's)")
+    ap.add_argument("--also_timeout", type=int, default=240,
+                    help="seconds the secondary (\"also\") runs may take before the headline result is reported "
+                         "without them and the process ends with status 3 (0 = no limit)")
+    ap.add_argument("--hip_graph", type=int, default=-1,
+                    help="1: record the whole step (fwd, bwd, collectives, optimizer) in a HIP graph and replay it; "
+                         "default: on for inception_v3_head (hundreds of short kernels per step), off otherwise")
+    ap.add_argument("--launch_timeout", type=int, default=0,
+                    help="launcher: seconds after which the rank processes are stopped (0 = no limit)")
+    args = ap.parse_args(argv)
+    if args.hip_graph < 0:
+        args.hip_graph = 1 if args.model == "inception_v3_head" else 0
+    return args
+
+
+# ====================================================================================================== launcher
+def launch_ranks(args, argv) -> int:
+    """Start ``args.gpus`` rank processes of this script and wait for them.  Runs in a process that has not
+    imported torch: nothing here initialises the GPU, the children are fresh interpreters."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DTFA_BENCH_LAUNCHED="1")
+        # rank 0's stdout carries the result line and is relayed; the other ranks' stdout joins stderr
+        # (the ranks stay in this process's group, so whoever stops the launcher's group stops them too)
+        procs.append(subprocess.Popen([sys.executable, "-u", script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line.decode("utf-8", "replace"))
+            sys.stdout.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    def on_term(signum, frame):
+        raise KeyboardInterrupt
+
+    signal.signal(signal.SIGTERM, on_term)
+
+    t0 = time.time()
+    status = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                r, c = bad[0]
+                print("bench.py launcher: rank %d exited with status %d; stopping the other ranks" % (r, c), file=sys.stderr)
+                status = c if c > 0 else 128 - c
+                break
+            if all(c == 0 for c in codes):
+                break
+            if args.launch_timeout and time.time() - t0 > args.launch_timeout:
+                print("bench.py launcher: ranks still running after %d s; stopping them" % args.launch_timeout, file=sys.stderr)
+                status = 124
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        status = 130
+    finally:
+        stop_all()
+        t.join(5)
+    return status
+
+
+# ====================================================================================================== one rank
+def mode_learning_rate(mode, staleness, world, base):
+    """Step size a distribution mode is run with.  Gradients applied late narrow the stable range under heavy-ball
+    momentum mu: with one step of delay, on a quadratic of curvature c the iteration
+    w' = (1 + mu) w - (mu + lr c) w_prev is stable only for lr c < 1 - mu, against lr c < 2 (1 + mu) without the
+    delay -- a 38x smaller range at mu = 0.9.  Measured on the fixed synthetic batch: 0.02 and 0.002 oscillate
+    upwards under a delay, 0.0005 descends.  ``async_ssp`` delays every gradient by ``staleness`` steps at any world
+    size; ``async_ps`` applies a gradient computed on parameters that are up to world - 1 pushes old (none in a
+    world of one, or in lock step)."""
+    delayed = (mode == "async_ssp" and staleness > 0) or (mode == "async_ps" and staleness != 0 and world > 1)
+    return base / 40 if delayed else base
 
 
 def run_config(args, model_name, batch, device, rank, world, mode=None):
     """W untimed + K timed complete training steps of one model; returns the whole-job images/s (max time over ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    from distributed_tensorflow_amd.models import build_model
+    from distributed_tensorflow_amd.ops import functional as F
+
     mode = mode or args.mode
     size = args.image_size or IMAGE_SIZE[model_name]
     torch.manual_seed(1234)
@@ -49,16 +186,20 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
         opt, lr, okw = "adam", 1e-3, {}
     else:
         # a fixed synthetic batch with random labels: a small constant rate keeps the loss finite at any world size
-        opt, lr, okw = "momentum", 0.02, {"momentum": 0.9, "weight_decay": 1e-4}
-        if mode == "async_ssp" and args.staleness > 0:
-            # gradients applied one step late under heavy-ball momentum mu: on a quadratic of curvature c the
-            # iteration w' = (1 + mu) w - (mu + lr c) w_prev is stable only for lr c < 1 - mu, against
-            # lr c < 2 (1 + mu) without the delay -- a 38x smaller range at mu = 0.9.  Measured on this fixed batch:
-            # 0.02 and 0.002 oscillate upwards, 0.0005 descends.
-            lr = lr / 40
-    engine = DataParallelEngine(model, mode=mode, optimizer=opt, lr=lr, opt_kwargs=okw,
-                                bucket_mb=args.bucket_mb, staleness=args.staleness, p2p_max_bytes=args.p2p_kb * 1024,
-                                grad_dtype={"fp32": torch.float32, "bf16": torch.bfloat16}[args.grad_dtype])
+        opt, okw = "momentum", {"momentum": 0.9, "weight_decay": 1e-4}
+        lr = mode_learning_rate(mode, args.staleness, world, 0.02)
+    grad_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[args.grad_dtype]
+    if mode == "async_ps":
+        from distributed_tensorflow_amd.parallel.xps import XgmiPSEngine
+
+        engine = XgmiPSEngine(model, optimizer=opt, lr=lr, opt_kwargs=okw, staleness=args.staleness, apply=args.ps_apply,
+                              grad_dtype=grad_dtype, timeout=args.ps_timeout)
+    else:
+        from distributed_tensorflow_amd.parallel.engine import DataParallelEngine
+
+        engine = DataParallelEngine(model, mode=mode, optimizer=opt, lr=lr, opt_kwargs=okw,
+                                    bucket_mb=args.bucket_mb, staleness=args.staleness, p2p_max_bytes=args.p2p_kb * 1024,
+                                    grad_dtype=grad_dtype)
     engine.measure_comm = not args.hip_graph  # (events cannot be timed inside a captured graph)
 
     # synthetic batch generated on the device (a 2048 x 224 x 224 host tensor per rank would cost seconds and GBs)
@@ -133,52 +274,31 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
         gc.collect()
         if device.type == "cuda":
             torch.cuda.synchronize()
+    if hasattr(engine, "close"):
+        if dist.is_initialized():
+            dist.barrier()   # (nobody leaves while a peer still pushes to it or pulls from it)
+        engine.close()
     return {"value": round(ips, 2), "ms_per_step": round(dt / args.steps * 1e3, 3), "final_loss": final_loss,
-            "first_loss": first_loss,
+            "first_loss": first_loss, "learning_rate": lr,
             "per_gpu_batch": batch, "global_batch": batch * world, "optimizer": opt,
             "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2**30, 2) if device.type == "cuda" else 0.0,
             "comm": comm}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="resnet50", choices=sorted(DEFAULT_BATCH))
-    ap.add_argument("--mode", default="sync_dp", choices=["sync_dp", "sharded_ps", "async_ssp"])
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default depends on the model)")
-    ap.add_argument("--bucket_mb", type=float, default=0.0,
-                    help="gradient bucket size in MiB (0: 32, or a quarter of the gradient for models under 64 MiB)")
-    ap.add_argument("--staleness", type=int, default=1)
-    ap.add_argument("--grad_dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="dtype of the gradient buckets (what the collectives move): bf16 halves the bytes on xGMI")
-    ap.add_argument("--p2p_kb", type=int, default=0,
-                    help="gradient buckets up to this many KiB use the one-shot xGMI mailbox all-reduce (sync_dp)")
-    ap.add_argument("--trunk_bn", default="batch", choices=["batch", "moving"],
-                    help="inception_v3_head: trunk batch-norm on batch statistics (reference) or frozen moving statistics")
-    ap.add_argument("--also", default="flower_cnn",
-                    help="second model measured after the headline one and reported under \"also\" ('' = none)")
-    ap.add_argument("--also_batch", type=int, default=0, help="per-GPU batch of the second model (default: its own)")
-    ap.add_argument("--also_modes", default="sharded_ps,async_ssp",
-                    help="distribution modes the headline model is measured in as well, reported under \"also\" ('' = none)")
-    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
-                    help="cpu: rehearse the multi-rank control flow over gloo (not a measurement)")
-    ap.add_argument("--image_size", type=int, default=0, help="square image size (default: the model's)")
-    ap.add_argument("--also_timeout", type=int, default=240,
-                    help="seconds the secondary (\"also\") runs may take before the headline result is reported "
-                         "without them (0 = no limit)")
-    ap.add_argument("--hip_graph", type=int, default=-1,
-                    help="1: record the whole step (fwd, bwd, collectives, optimizer) in a HIP graph and replay it; "
-                         "default: on for inception_v3_head (hundreds of short kernels per step), off otherwise")
-    args = ap.parse_args()
-    if args.hip_graph < 0:
-        args.hip_graph = 1 if args.model == "inception_v3_head" else 0
+ALSO_KEYS = ("value", "ms_per_step", "per_gpu_batch", "global_batch", "first_loss", "final_loss", "learning_rate")
+
+
+def run_rank(args) -> int:
+    import gc
+    import threading
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run, any N
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under a launcher, any N
     if args.device == "cpu":
         # plumbing rehearsal only (tests/test_parallel.py): the same control flow over gloo on fp32 CPU tensors
         device = torch.device("cpu")
@@ -188,21 +308,29 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X GPU")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) are visible (one rank per GPU)"
+                             % (rank, local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
         if world > 1 or launched:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d; reporting WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        # a record that says n_gpus = 1 for a run asked to use 8 would be worthless: refuse instead of warning
+        raise SystemExit("bench.py: --gpus %d but the job has %d rank(s); start it as `python bench.py --gpus %d` "
+                         "(it launches the ranks itself) or under torch.distributed.run with --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus, args.gpus))
+    devices = [local_rank]
+    if dist.is_initialized():
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local_rank if device.type == "cuda" else -1)
+        devices = gathered
 
     head = run_config(args, args.model, args.batch or DEFAULT_BATCH[args.model], device, rank, world)
-    import gc
 
     also = {}
-
-    import threading
-
     report_lock = threading.Lock()
     reported = []
 
@@ -211,6 +339,7 @@ def main():
             if reported or rank != 0:
                 return
             reported.append(True)
+            secondary = dict(also)
         print(json.dumps({
             "metric": "train images/sec (whole node)",
             "value": head["value"],
@@ -228,25 +357,34 @@ def main():
             "first_loss": head["first_loss"],
             "config": {"model": args.model, "global_batch": head["global_batch"], "per_gpu_batch": head["per_gpu_batch"],
                        "image_size": args.image_size or IMAGE_SIZE[args.model], "num_classes": 5, "parallelism": "dp%d" % world,
-                       "mode": args.mode, "optimizer": head["optimizer"], "hip_graph": bool(args.hip_graph)},
+                       "mode": args.mode, "optimizer": head["optimizer"], "learning_rate": head["learning_rate"],
+                       "hip_graph": bool(args.hip_graph)},
             "peak_mem_gb": head["peak_mem_gb"],
-            # communication of the headline run: RCCL world, gradient buckets (count / bytes each / dtype) and the
-            # time per step the compute stream spent waiting for collectives that backward did not hide
-            "rccl_world": world if dist.is_initialized() else 0,
+            # communication of the headline run: size of the process group (RCCL on GPUs), the GPU index of every
+            # rank, gradient buckets (count / bytes each / dtype) and the time per step the compute stream spent
+            # waiting for collectives that backward did not hide
+            "rccl_world": dist.get_world_size() if dist.is_initialized() else 0,
+            "rank_devices": devices,
             "comm": head["comm"],
-            "also": also,
+            "also": secondary,
         }), flush=True)
 
     # The headline number is measured; the secondary runs below must not be able to lose it.  If one of them
     # hangs (a rank that failed inside a collective leaves its peers waiting), the watchdog reports the headline
-    # with whatever secondary results exist and ends the process.
+    # with whatever secondary results exist and ends the process with a non-zero status: the hang is on record.
     done = threading.Event()
 
     def watchdog():
         if not done.wait(args.also_timeout):
-            also["error"] = "secondary runs exceeded %d s and were abandoned" % args.also_timeout
+            with report_lock:
+                also["error"] = "secondary runs exceeded %d s and were abandoned" % args.also_timeout
             report()
-            os._exit(0)
+            sys.stdout.flush()
+            os._exit(3)
+
+    def put(key, value):
+        with report_lock:
+            also[key] = value
 
     if args.also_timeout > 0:
         threading.Thread(target=watchdog, daemon=True).start()
@@ -257,21 +395,26 @@ def main():
             torch.cuda.empty_cache()
         try:
             r = run_config(args, args.also, args.also_batch or DEFAULT_BATCH[args.also], device, rank, world)
-            also[args.also] = {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "first_loss", "final_loss")}
+            put(args.also, {k: r[k] for k in ALSO_KEYS})
         except Exception as e:  # noqa: BLE001 -- the headline number stands on its own
-            also[args.also] = {"error": "%s: %s" % (type(e).__name__, e)}
-    # the headline model in the other two distribution modes (sharded parameter ownership: reduce-scatter +
-    # all-gather; staleness-bounded asynchronous updates), same batch, same K / W
+            put(args.also, {"error": "%s: %s" % (type(e).__name__, e)})
+    # the headline model in the other distribution modes (sharded parameter ownership: reduce-scatter + all-gather;
+    # staleness-bounded delayed all-reduce; the GPU-resident asynchronous parameter server), same batch, same K / W
     for other in [m for m in args.also_modes.split(",") if m and m != args.mode and not args.hip_graph]:
+        if other == "async_ps" and device.type != "cuda":
+            continue   # (its parameters live in GPU memory)
         gc.collect()
         if device.type == "cuda":
             torch.cuda.empty_cache()
         key = "%s/%s" % (args.model, other)
         try:
             r = run_config(args, args.model, head["per_gpu_batch"], device, rank, world, mode=other)
-            also[key] = {k: r[k] for k in ("value", "ms_per_step", "per_gpu_batch", "global_batch", "first_loss", "final_loss")}
+            d = {k: r[k] for k in ALSO_KEYS}
+            if other == "async_ps":
+                d["comm"] = r["comm"]
+            put(key, d)
         except Exception as e:  # noqa: BLE001
-            also[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            put(key, {"error": "%s: %s" % (type(e).__name__, e)})
     done.set()
     report()
     if dist.is_initialized():
@@ -280,7 +423,16 @@ def main():
             torch.cuda.synchronize()
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

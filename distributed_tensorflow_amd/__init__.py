@@ -13,4 +13,12 @@ Package layout::
     utils/     flags, cluster spec, logging
 """
 
+import os as _os
+
+# Peer-mapped device memory (RCCL over xGMI, the hipIpc-mapped mailboxes of parallel/p2p.py and parallel/xps.py) needs
+# the dmabuf IPC path of the ROCm runtime; the legacy path fails with ``hipIpcGetMemHandle: invalid argument``.  The
+# runtime reads the variable when it initialises, which is at the first HIP call, so importing the package before
+# that is early enough.
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 __version__ = "0.1.0"

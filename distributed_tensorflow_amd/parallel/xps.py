@@ -268,6 +268,32 @@ class XgmiPSEngine:
                 "torn_pulls": out[5], "dropped_pushes": out[6], "timeouts": out[7], "dead_mask": out[8],
                 "pushes": out[9], "done_mask": out[10], "clocks": [out[16 + r] for r in range(self.world)]}
 
+    # -- communication accounting (same interface as DataParallelEngine; bench.py reports it) ----------------
+    measure_comm = False
+
+    def reset_comm_stats(self) -> None:
+        self._stats_base = self.state()
+
+    def comm_stats(self) -> dict:
+        """Protocol counters since :meth:`reset_comm_stats` (synchronises the stream): what was pushed, what was
+        dropped or torn, which peers were written off."""
+        st = self.state()
+        base = getattr(self, "_stats_base", None) or {}
+        gbytes = sum(sh.group.grad.numel() * sh.group.grad.element_size() for sh in self.shards)
+        pbytes = sum(sh.group.total * 4 for sh in self.shards)
+
+        def since(k):
+            return int(st[k]) - int(base.get(k, 0))
+
+        return {"collective": False, "world": self.world, "mode": self.mode, "backend": self.backend,
+                "apply": self.apply, "staleness": self.staleness,
+                "grad_dtype": str(self.shards[0].group.grad.dtype).replace("torch.", "") if self.shards else None,
+                "groups": len(self.shards), "pushed_bytes_per_step": int(gbytes), "pulled_bytes_per_step": int(pbytes),
+                "pushes": since("pushes"), "applied": since("applied"), "status": int(st["status"]),
+                "dropped_pushes": since("dropped_pushes"), "torn_pulls": since("torn_pulls"),
+                "timeouts": since("timeouts"), "dead_mask": int(st["dead_mask"]), "done_mask": int(st["done_mask"]),
+                "clocks": st["clocks"]}
+
     @property
     def global_step(self) -> int:
         """Optimizer steps applied to shard 0 (the analogue of ``global_step`` living on ps task 0)."""

@@ -5,6 +5,8 @@
 #   ./run.sh [num_workers] [extra train_dataset.py flags...]
 set -e
 cd "$(dirname "$0")"
+# peer-mapped GPU memory (--ps_backend=xgmi, RCCL) needs the dmabuf IPC path of the ROCm runtime
+export HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}
 NW=${1:-2}
 shift || true
 PS_PORT=${PS_PORT:-2223}

@@ -83,3 +83,32 @@ def test_resnet50_bench_under_torchrun_one_rank(extra):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["config"]["model"] == "resnet50" and out["value"] > 0 and out["final_loss"] < 5.0
     assert out["comm"]["collective"] is True and out["comm"]["buckets"] >= 1
+
+
+@pytest.mark.parametrize("extra,launcher", [
+    (["--staleness", "1"], False),
+    (["--staleness", "0", "--ps_apply", "aggregate"], True),
+    (["--staleness", "-1", "--hip_graph", "1", "--grad_dtype", "bf16"], True),
+])
+def test_bench_async_ps_world_of_one(extra, launcher):
+    """``--mode async_ps``: the GPU-resident parameter server (gate, pull, push into the owner's mailbox, apply on
+    the owner, commit) as the headline run, started with and without a launcher; its protocol counters are part of
+    the record."""
+    cmd = [sys.executable]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", _port()]
+    cmd += ["bench.py", "--gpus", "1", "--model", "flower_cnn", "--batch", "32", "--steps", "4", "--warmup", "2",
+            "--mode", "async_ps", "--also", "", "--also_modes", ""] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert r.returncode == 0, _failure_text(r.stdout)
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["final_loss"] < 5.0
+    assert out["config"]["mode"] == "async_ps" and out["rank_devices"] == [0]
+    comm = out["comm"]
+    assert comm["mode"] == "async_ps" and comm["backend"] == "xgmi" and comm["world"] == 1
+    assert comm["pushes"] == 4 * comm["groups"] or comm["pushes"] == 4   # (counters of the first group's region)
+    assert comm["applied"] == 4
+    assert comm["dropped_pushes"] == 0 and comm["torn_pulls"] == 0 and comm["timeouts"] == 0 and comm["status"] == 0
+    assert comm["pushed_bytes_per_step"] > 0 and comm["pulled_bytes_per_step"] > 0

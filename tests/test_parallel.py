@@ -259,7 +259,7 @@ def test_bucket_ready_callbacks_fire_once_per_bucket():
     assert len(set(fired)) == len(fired)
 
 
-def _run_bench_cpu(world, extra, timeout=300):
+def _run_bench_cpu(world, extra, timeout=300, expect_status=0):
     """bench.py launched the way the driver launches it (one rank per device under torch.distributed.run), over gloo
     on CPU tensors: the control flow of a multi-rank run -- rendezvous, barriers around the timed region, the MAX over
     ranks, the secondary runs, one JSON line from rank 0 -- rehearsed without GPUs."""
@@ -277,8 +277,65 @@ def _run_bench_cpu(world, extra, timeout=300):
            "--model", "flower_cnn", "--batch", "4", "--image_size", "32", "--steps", "2", "--warmup", "1"] + extra
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=root)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    # (torch.distributed.run reports any failed rank as status 1: ``expect_status=None`` asks for "not zero")
+    ok = r.returncode != 0 if expect_status is None else r.returncode == expect_status
+    assert ok and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     return json.loads(lines[0])
+
+
+def _run_bench_self_launched(args, timeout=300):
+    """``python bench.py --gpus N ...`` with no launcher and no RANK / WORLD_SIZE in the environment: bench.py starts
+    its rank processes itself."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=root, env=env)
+
+
+def test_bench_starts_its_own_ranks():
+    """One command launches the job (the reference: distributed/run.sh): ``--gpus 2`` without a launcher trains on two
+    ranks and says so, instead of silently training on one."""
+    import json
+
+    r = _run_bench_self_launched(["--gpus", "2", "--device", "cpu", "--model", "flower_cnn", "--batch", "4", "--image_size",
+                                  "32", "--steps", "2", "--warmup", "1", "--also", "", "--also_modes", ""])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_world"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["global_batch"] == 8 and len(d["rank_devices"]) == 2
+    assert d["comm"]["collective"] and d["comm"]["world"] == 2
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """A rank that fails ends the job with a non-zero status and no result line (here the ranks ask for GPUs on a
+    machine without one)."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs are visible: the ranks would start")
+    r = _run_bench_self_launched(["--gpus", "2", "--device", "cuda", "--steps", "1", "--warmup", "0", "--also", "",
+                                  "--also_modes", ""], timeout=120)
+    assert r.returncode != 0 and "{" not in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+
+
+def test_bench_refuses_a_world_that_is_not_the_one_asked_for():
+    """``--gpus 4`` inside a job of two ranks must not produce a record: it ends with an error instead."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--device", "cpu", "--model",
+                        "flower_cnn", "--batch", "4", "--image_size", "32", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, cwd=root, env=env)
+    assert r.returncode != 0 and "--gpus 4" in r.stderr and "{" not in r.stdout, (r.returncode, r.stderr[-500:])
 
 
 def test_bench_two_ranks_over_gloo():
@@ -293,8 +350,9 @@ def test_bench_two_ranks_over_gloo():
 
 def test_bench_reports_headline_when_secondary_runs_exceed_their_time():
     """The watchdog: secondary runs that do not finish in ``--also_timeout`` seconds are abandoned and the headline
-    result is still printed (exactly once) with a zero exit status."""
-    d = _run_bench_cpu(2, ["--also", "resnet50", "--also_batch", "16", "--also_modes", "sharded_ps", "--also_timeout", "1"])
+    result is still printed (exactly once); the ranks end with status 3, so that the abandoned runs are on record."""
+    d = _run_bench_cpu(2, ["--also", "resnet50", "--also_batch", "16", "--also_modes", "sharded_ps", "--also_timeout", "1"],
+                       expect_status=None)
     assert d["value"] > 0 and "exceeded" in d["also"].get("error", ""), d["also"]
 
 
