@@ -21,4 +21,9 @@ import os as _os
 # that is early enough.
 _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+# The communicator's flight recorder (a ring of the last collectives and whether the watchdog thread has retired them)
+# is what train/graph.py reads to know that no eager collective is still being polled when a step graph is captured.
+# Read when the process group is created.
+_os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
+
 __version__ = "0.1.0"

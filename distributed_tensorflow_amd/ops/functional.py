@@ -278,15 +278,32 @@ _STAT_CHUNK = 1 << 16   # fp64 values per buffer (512 KB); Inception-v3 needs ~2
 
 
 class _StatScope:
+    """One zeroed fp64 buffer per forward pass.  The buffer is filled when the scope is entered, on the entering
+    stream, so the fill precedes every fork of ``run_branches``; a stream other than the filling one waits for the
+    fill's event before it hands a slice to a kernel (inside a graph capture that wait is the edge from the fill node
+    to the branch's convolution nodes -- without it a replay may zero the buffer after a side branch has added its
+    sums).  A buffer that runs out is replaced the same way, fill + event on the stream that needed it."""
+
     def __init__(self, device):
         self.device = device
         self.buf = None
         self.used = 0
+        self.fill_stream = None
+        self.fill_event = None
+        self._fill(_STAT_CHUNK)
+
+    def _fill(self, n: int) -> None:
+        self.buf = torch.zeros(max(_STAT_CHUNK, n), dtype=torch.float64, device=self.device)
+        self.used = 0
+        self.fill_stream = torch.cuda.current_stream(self.device)
+        self.fill_event = self.fill_stream.record_event()
 
     def take(self, n: int) -> torch.Tensor:
-        if self.buf is None or self.used + n > self.buf.numel():
-            self.buf = torch.zeros(max(_STAT_CHUNK, n), dtype=torch.float64, device=self.device)
-            self.used = 0
+        if self.used + n > self.buf.numel():
+            self._fill(n)
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.fill_stream:
+            cur.wait_event(self.fill_event)
         out = self.buf[self.used:self.used + n]
         self.used += (n + 1) & ~1   # keep slices 16-byte aligned
         return out

@@ -24,12 +24,68 @@ from __future__ import annotations
 
 from typing import Callable, Optional, Tuple
 
+import os
 import time
 
 import torch
 import torch.distributed as dist
 
 from ..ops import kernels as K
+
+
+# Collectives recorded inside a capture are never handed to the communicator's watchdog, so they never retire: their
+# record ids are remembered here and not waited for by a later capture.
+_captured_records: set = set()
+
+
+def _collective_records():
+    """(record id, retired) of every collective the communicator's flight recorder knows, or None when the recorder is
+    off (TORCH_FR_BUFFER_SIZE = 0) or its dump cannot be read."""
+    try:
+        import pickle
+
+        from torch._C._distributed_c10d import _dump_nccl_trace
+
+        entries = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=False)).get("entries")
+    except Exception:  # noqa: BLE001 -- an unreadable dump is "no information", handled by the caller
+        return None
+    if entries is None:
+        return None
+    return [(e.get("record_id"), bool(e.get("retired"))) for e in entries]
+
+
+def retire_eager_collectives(timeout: float = 20.0) -> None:
+    """Return once the communicator's watchdog thread holds no collective of the eager steps any more.
+
+    The watchdog retires finished collectives by querying their events from its own thread, every 100 ms.  A
+    collective of the eager warm-up steps that it has not retired when a capture starts is queried DURING the capture,
+    once the communicator's stream has joined it -- and HIP refuses the query of an event whose stream is capturing
+    ("operation not permitted on an event last recorded in a capturing stream"), which the watchdog turns into an abort
+    of the process.  Waiting for the device is not enough: a finished collective stays in the watchdog's list until
+    its next look.  The communicator's flight recorder says when the watchdog HAS looked: it marks a collective
+    ``retired`` at the moment the watchdog drops it.  So the capture starts only when every recorded collective
+    that was issued outside a capture is retired; with the device idle that takes at most one watchdog period, and
+    no timing assumption is involved (the loop ends on the recorder's state, the timeout only bounds a defect).
+    The package turns the recorder on (``distributed_tensorflow_amd/__init__.py``); should it be off nevertheless,
+    this raises instead of guessing."""
+    t0 = time.monotonic()
+    while True:
+        recs = _collective_records()
+        if recs is None:
+            raise RuntimeError("the communicator's flight recorder is off (TORCH_FR_BUFFER_SIZE=0): a step graph "
+                               "that holds collectives cannot be captured safely; unset the variable or capture before "
+                               "the process group is created")
+        pending = [i for i, retired in recs if not retired and i not in _captured_records]
+        if not pending:
+            return
+        if time.monotonic() - t0 > timeout:
+            raise RuntimeError("collectives %s of the eager steps were not retired within %.0f s" % (pending[:8], timeout))
+        os.sched_yield()   # (the loop ends on the recorder's state; this only gives the core away between looks)
+
+
+def note_captured_collectives() -> None:
+    recs = _collective_records() or []
+    _captured_records.update(i for i, retired in recs if not retired)
 
 
 class StepGraph:
@@ -50,13 +106,7 @@ class StepGraph:
         eng = self.engine
         torch.cuda.synchronize()
         if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
-            # The communicator's watchdog thread retires finished collectives by polling their events every 100 ms.
-            # A collective of the eager steps before this capture that it has not looked at yet would be polled
-            # DURING the capture, once the communicator's stream has joined it -- and HIP refuses a query of an
-            # event whose stream is capturing ("operation not permitted on an event last recorded in a capturing
-            # stream"), which the watchdog turns into an abort of the process (seen as an intermittent SIGABRT of
-            # captured sync_dp / sharded_ps runs).  The device is idle here, so a few watchdog periods empty its list.
-            time.sleep(0.35)
+            retire_eager_collectives()
         eng.prepare_step()
         # Other threads keep issuing HIP calls while the capture runs -- RCCL's watchdog polls events of earlier
         # work, the input pipeline's helper thread uploads the next batch on its copy stream -- and
@@ -68,6 +118,8 @@ class StepGraph:
             total.backward()
             eng.finish_step(prepared=True)
             self.outputs = tuple(o.detach() if isinstance(o, torch.Tensor) else o for o in out)
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            note_captured_collectives()
 
     def compatible(self, images: torch.Tensor, labels: torch.Tensor) -> bool:
         return (images.shape == self.images.shape and images.dtype == self.images.dtype

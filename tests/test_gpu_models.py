@@ -364,3 +364,45 @@ def test_inception_trunk_statistics_in_accumulators_match_partial_rows(monkeypat
     assert (a - b).abs().mean() <= 2e-3 * b.abs().mean() + 1e-4
     torch.testing.assert_close(a, b, rtol=5e-2, atol=5e-2)
     torch.testing.assert_close(stats[0], stats[1], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("captured", [False, True])
+def test_statistics_accumulators_with_forked_branches(monkeypatch, captured):
+    """The accumulator buffer is zeroed before the branches of a block fork onto side streams, eagerly
+    (DTFA_BRANCH_PARALLEL=always) and inside a HIP graph replayed several times: the features equal those of the
+    partial-rows path on one stream."""
+    torch.manual_seed(0)
+    x, _ = _images(4, 299, seed=7)
+    x = x.cuda().bfloat16()
+    torch.manual_seed(1)
+    model = build_model("inception_v3_head", device="cuda").train()
+
+    def features():
+        with torch.no_grad(), F.stat_scope(x.device):
+            return dict(model.trunk.endpoints(x, fuse_pools=True))["Mixed_7c"].float()
+
+    monkeypatch.setattr(F, "BRANCH_PARALLEL", "never")
+    monkeypatch.setattr(F, "STAT_ACC_MAX_ROWS", 0)
+    ref = features()
+    monkeypatch.setattr(F, "STAT_ACC_MAX_ROWS", 1 << 16)
+    monkeypatch.setattr(F, "BRANCH_PARALLEL", "always")
+    if not captured:
+        outs = [features() for _ in range(3)]
+    else:
+        features()   # plans and workspaces exist before the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                out = features()
+        outs = []
+        for _ in range(4):
+            g.replay()
+            torch.cuda.synchronize()
+            outs.append(out.clone())
+    for a in outs:
+        assert torch.isfinite(a).all()
+        assert (a - ref).abs().mean() <= 2e-3 * ref.abs().mean() + 1e-4
+        torch.testing.assert_close(a, ref, rtol=5e-2, atol=5e-2)
