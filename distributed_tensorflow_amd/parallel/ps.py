@@ -198,10 +198,16 @@ class ParameterServer:
                         if not self.initialized:  # first initialiser wins; later ones are ignored
                             self.params = torch.from_numpy(blob[:n_par])
                             self.grad = torch.zeros_like(self.params)
+                            lr = float(meta.get("lr", 1e-3))
+                            decay = meta.get("lr_decay")   # [decay_steps, decay_rate]: the schedule runs on the ps,
+                            if decay:                      # on its own count of applied steps
+                                from ..optim.schedules import exponential_decay
+
+                                lr = exponential_decay(lr, int(decay[0]), float(decay[1]))
                             self.optimizer = make_optimizer(meta.get("optimizer", "adam"),
                                                             [OptRegion("ps%d" % self.ps_index, self.params, self.grad,
                                                                        None, False)],
-                                                            float(meta.get("lr", 1e-3)), **meta.get("opt_kwargs", {}))
+                                                            lr, **meta.get("opt_kwargs", {}))
                             self.global_step = int(meta.get("global_step", 0))
                             self.optimizer.step_count = self.global_step
                             if nslots:  # a resumed run: the chief hands over the restored optimizer state too
@@ -395,11 +401,13 @@ class PSWorkerEngine:
 
     def __init__(self, model, ps_addresses: List[Tuple[str, int]], worker_index: int, is_chief: bool, *,
                  optimizer: str = "adam", lr: float = 1e-3, opt_kwargs: Optional[dict] = None,
-                 connect_timeout: float = 60.0, initial_global_step: int = 0, defer_init: bool = False):
+                 connect_timeout: float = 60.0, initial_global_step: int = 0, defer_init: bool = False,
+                 lr_decay: Optional[Tuple[int, float]] = None):
         """``defer_init`` (chief only): connect, but leave the ps tasks uninitialised until :meth:`initialize`,
         so that a checkpoint can be restored into this engine first and the ps tasks start from the restored
         variables, optimizer slots and global step -- non-chief workers blocked in ``wait_init`` never see the
-        un-restored values."""
+        un-restored values.  ``lr_decay`` = (decay_steps, decay_rate): exponential decay of ``lr`` over the global
+        step, evaluated on the ps tasks (where the optimizer runs); the chief hands it over at initialisation."""
         from .flat import FlatParams
 
         self.model = model
@@ -407,6 +415,7 @@ class PSWorkerEngine:
         self.is_chief = is_chief
         self.flat = FlatParams(model, bucket_mb=1 << 20)  # one bucket per group: no collectives here
         self.lr = lr
+        self.lr_decay = (int(lr_decay[0]), float(lr_decay[1])) if lr_decay else None
         self.mode = "async_ps"
         self.clock = 0
         self._prepared = False
@@ -465,7 +474,8 @@ class PSWorkerEngine:
         if self.is_chief:
             for i, c in enumerate(self.conns):
                 payload = self._state_payload(i, self._pending_slots, {"optimizer": self._optimizer_name, "lr": self.lr,
-                                                                       "opt_kwargs": self._opt_kwargs})
+                                                                       "opt_kwargs": self._opt_kwargs,
+                                                                       "lr_decay": list(self.lr_decay) if self.lr_decay else None})
                 c.call(OP_INIT, 0, payload)
             self._pending_slots = {}
         else:
@@ -477,6 +487,8 @@ class PSWorkerEngine:
         self.pull()
 
     def current_lr(self) -> float:
+        if self.lr_decay:
+            return self.lr * self.lr_decay[1] ** (self.global_step / self.lr_decay[0])
         return self.lr
 
     # -- (un)packing -------------------------------------------------------------

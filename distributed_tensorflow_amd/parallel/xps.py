@@ -1,34 +1,53 @@
 """GPU-resident asynchronous parameter server over one-sided peer memory (``csrc/hip/xps.hip``).
 
 The reference's distribution strategy is asynchronous between-graph replication: variables and
-``ApplyAdam`` live on a ps task, each worker pulls, computes and pushes on its own
+``ApplyAdam`` live on ps tasks, each worker pulls, computes and pushes on its own
 (recognition_flower/distributed/train_dataset.py:141-149,162-165), and a worker never depends on another
 worker being alive (``device_filters``, train_dataset.py:172-174).  :mod:`parallel.ps` realises that with ps
-*processes* over TCP.  This engine is the same contract on one xGMI node without a ps process, a host copy
-or a collective on the data path:
+*processes* over TCP.  This module is the same contract on one xGMI node without a host copy or a collective on
+the data path: the variables live in GPU memory that every process maps through ``hipIpc``.
 
-* every rank is a worker and **owns** shard ``r`` (1/N) of each flat parameter group: fp32 master values and
-  optimizer slots live in fine-grained device memory that all peers map through ``hipIpc``;
-* **push**: a worker copies shard ``o`` of its gradient into its mailbox slot in owner ``o``'s memory and
-  raises a sequence word there (direct peer stores, one xGMI link per owner);
-* **apply**: at the end of its own step an owner consumes whatever has arrived -- one fused Adam / momentum
-  step per arrived gradient (``apply="per_push"``, TensorFlow's ps semantics) or, in lock-step rounds, one step
-  on the rank-ordered sum of the round (``apply="aggregate"``, the arithmetic of synchronous data
-  parallelism) -- and publishes a new parameter version;
-* **pull**: a worker reads the current version of every shard straight out of its owner's memory;
+* an **owner** holds shard ``o`` (1/``nown``) of each flat parameter group: fp32 master values, optimizer slots
+  and one pair of mailbox slots per worker, in fine-grained device memory (its *region*);
+* **push**: a worker copies shard ``o`` of its gradient into its mailbox slot in region ``o`` and raises a
+  sequence word there (direct peer stores, one xGMI link per owner);
+* **apply**: whoever applies a region consumes what has arrived -- one fused Adam / momentum step per arrived
+  gradient (``apply="per_push"``, TensorFlow's ps semantics) or, in lock-step rounds, one step on the
+  worker-ordered sum of the round (``apply="aggregate"``, the arithmetic of synchronous data parallelism) -- and
+  publishes a new parameter version;
+* **pull**: a worker reads the current version of every shard straight out of its region;
 * **bounded staleness**: a worker whose clock is more than ``staleness`` steps ahead of the slowest live
-  worker waits on the peers' clock words (``-1`` = unbounded, ``0`` = lock step); a peer that does not move
-  for ``timeout`` seconds, or has left, stops counting, so a dead worker delays the others once, by one
-  timeout, and never again.
+  worker waits on the workers' clock words (``-1`` = unbounded, ``0`` = lock step); a worker that does not move
+  for ``timeout`` seconds, or has left, stops counting.
+
+Two deployments:
+
+**ps tasks own the variables** (:class:`XgmiPSServer` + :class:`XgmiPSEngine` with a :class:`XpsCluster`): the
+reference's topology.  A ps process allocates its regions, publishes their IPC handles in a key-value store hosted by
+ps task 0 and then only runs the apply loop; workers are pure clients.  A worker that dies takes nothing with it,
+a worker may join late (it maps the handles from the store, takes the slowest live worker's clock and pulls the
+current values), and the chief stops the ps tasks when it finishes.
+
+**no ps tasks** (:class:`XgmiPSEngine` on a process group, e.g. under ``torchrun`` / ``bench.py``): every worker
+process also owns a shard.  When such a process leaves or dies, its region stays mapped in the other processes and
+the lowest-ranked live process takes it over *in place* (compare-and-swap on the region's ``adopter`` word, then
+collect / apply / commit with its own kernels through the peer mapping): every shard keeps training, pushers and
+pullers notice nothing.  Gradients pushed to a dead owner between its death and the take-over wait in their
+mailbox slots; a worker whose slot in that region stays full for a whole ``timeout`` drops that shard of its
+gradient (counted in ``dropped_pushes``) instead of blocking.
 
 All device work of a step is kernels on the current stream that read their sequence numbers from device
-memory, so a step is the same launch sequence every time (HIP-graph capturable).  The process group is used
-once, to exchange the IPC handles.  The worker set is fixed at start-up; workers may finish or die at any time.
+memory, so a step is the same launch sequence every time (HIP-graph capturable).  Nothing here uses a collective
+on the data path; the process group (or the store) only carries IPC handles and the initial values at start-up.
 """
 from __future__ import annotations
 
 import ctypes as C
+import datetime
+import json
 import math
+import time
+from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import torch
@@ -40,18 +59,25 @@ from ..optim.fused import decay_spec
 from ..optim.schedules import Schedule, constant
 from .flat import FlatParams
 
+MAX_OWNERS = 16
+MAX_WORKERS = 16
+
 _SIGS = {
-    "dtfa_xps_create": [C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_void_p)],
+    "dtfa_xps_create": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_double,
+                        C.POINTER(C.c_void_p)],
     "dtfa_xps_handle": [C.c_void_p, C.c_char_p],
     "dtfa_xps_connect": [C.c_void_p, C.c_char_p],
-    "dtfa_xps_set_shard": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p],
+    "dtfa_xps_set_shard": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p],
+    "dtfa_xps_join": [C.c_void_p, C.c_void_p],
     "dtfa_xps_gate": [C.c_void_p, C.c_int, C.c_void_p],
     "dtfa_xps_pull": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "dtfa_xps_push": [C.c_void_p, C.c_void_p, C.c_void_p],
     "dtfa_xps_apply": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
-                       C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p],
     "dtfa_xps_leave": [C.c_void_p, C.c_void_p],
+    "dtfa_xps_shutdown": [C.c_void_p, C.c_void_p],
     "dtfa_xps_read_slot": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "dtfa_xps_report": [C.c_void_p, C.POINTER(C.c_uint)],
     "dtfa_xps_state": [C.c_void_p, C.POINTER(C.c_uint), C.c_void_p],
 }
 _sigs_done = False
@@ -71,127 +97,254 @@ def _lib():
     return L
 
 
-class _Shard:
-    """The peer-visible region of one flat group on this rank (context handle + sizes)."""
+@dataclass
+class XpsCluster:
+    """ps tasks own the variables: where the rendezvous store lives (ps task 0 hosts it) and who takes part."""
 
-    def __init__(self, group, world, rank, nslot, grad_is_bf16, timeout, pg):
-        self.group = group
-        self.piece = group.total // world
+    store_host: str
+    store_port: int
+    num_ps: int
+    num_workers: int
+    connect_timeout: float = 120.0
+
+    def store(self, is_master: bool = False):
+        return dist.TCPStore(self.store_host, int(self.store_port), None, is_master,
+                             timeout=datetime.timedelta(seconds=self.connect_timeout), wait_for_workers=False)
+
+
+def _state_dict(out, nown: int, nwrk: int) -> dict:
+    return {"clock": out[0], "version": out[1], "applied": out[2], "global_step": out[15], "applied_shard0": out[3],
+            "status": out[4], "torn_pulls": out[5], "dropped_pushes": out[6], "timeouts": out[7], "dead_mask": out[8],
+            "pushes": out[9], "done_mask": out[10], "adopted_mask": out[11], "joined_mask": out[12],
+            "shutdown": out[13], "written_off_regions": out[14],
+            "clocks": [out[16 + w] for w in range(nwrk)], "applied_per_shard": [out[32 + o] for o in range(nown)],
+            "adopters": [out[48 + o] for o in range(nown)], "consumed": [out[64 + w] for w in range(nwrk)],
+            "arrived": [out[80 + w] for w in range(nwrk)]}
+
+
+def _opt_config(optimizer: str, opt_kwargs: Optional[dict]) -> dict:
+    kw = dict(opt_kwargs or {})
+    name = optimizer.lower()
+    if name == "adam":
+        return {"kind": 0, "nslot": 2, "b1": kw.get("beta1", 0.9), "b2": kw.get("beta2", 0.999), "eps": kw.get("eps", 1e-8),
+                "mu": 0.0, "wd": 0.0, "nesterov": False, "slots": ["Adam", "Adam_1"]}
+    if name in ("momentum", "sgd"):
+        return {"kind": 1, "nslot": 1, "b1": 0.0, "b2": 0.0, "eps": 0.0, "mu": kw.get("momentum", 0.9),
+                "wd": kw.get("weight_decay", 0.0), "nesterov": bool(kw.get("nesterov", False)), "slots": ["Momentum"]}
+    raise ValueError("unknown optimizer %r" % optimizer)
+
+
+class _Region:
+    """Native context of one flat group in this process: the own region (if this process owns a shard) and the
+    mapped regions of all owners."""
+
+    def __init__(self, name: str, total: int, grad_is_bf16: bool, nown: int, nwrk: int, oidx: int, widx: int, nslot: int,
+                 timeout: float, device):
+        self.name = name
+        self.total = int(total)
+        self.piece = self.total // nown
+        if self.piece * nown != self.total or self.piece % 8:
+            raise ValueError("group %s: %d values do not split into %d shards of whole 32-byte vectors" % (name, total, nown))
         self.ctx = C.c_void_p()
-        L = _lib()
-        hipk.check(L.dtfa_xps_create(world, rank, self.piece, nslot, int(grad_is_bf16), float(timeout), C.byref(self.ctx)),
-                   "xps_create")
+        hipk.check(_lib().dtfa_xps_create(nown, nwrk, oidx, widx, self.piece, nslot, int(grad_is_bf16), float(timeout),
+                                          C.byref(self.ctx)), "xps_create")
+        self.hyper = torch.zeros(2, dtype=torch.float32, device=device)
+        self.no_decay_all = False
+
+    def handle(self) -> bytes:
         buf = C.create_string_buffer(64)
-        hipk.check(L.dtfa_xps_handle(self.ctx, buf), "xps_handle")
-        handles = [None] * world
-        if world > 1:
-            dist.all_gather_object(handles, buf.raw, group=pg)
-        else:
-            handles = [buf.raw]
-        hipk.check(L.dtfa_xps_connect(self.ctx, b"".join(handles)), "xps_connect")
-        self.hyper = torch.zeros(2, dtype=torch.float32, device=group.master.device)
+        hipk.check(_lib().dtfa_xps_handle(self.ctx, buf), "xps_handle")
+        return buf.raw
+
+    def connect(self, handles: List[bytes]) -> None:
+        hipk.check(_lib().dtfa_xps_connect(self.ctx, b"".join(handles)), "xps_connect")
+
+    def state(self, stream: int, nown: int, nwrk: int) -> dict:
+        out = (C.c_uint * 96)()
+        hipk.check(_lib().dtfa_xps_state(self.ctx, out, stream), "xps_state")
+        return _state_dict(out, nown, nwrk)
+
+    def report(self):
+        out = (C.c_uint * 4)()
+        _lib().dtfa_xps_report(self.ctx, out)
+        return out[0], out[1], out[2]
 
 
 class XgmiPSEngine:
-    """Worker + shard-owner engine with the ``begin_step`` / ``finish_step`` interface of the other engines.
+    """Worker (and, without ps tasks, shard-owner) engine with the ``begin_step`` / ``finish_step`` interface of the
+    other engines.
 
     ``staleness``: -1 unbounded (the reference), 0 lock step, s > 0 stale-synchronous.  ``apply``: ``per_push`` |
-    ``aggregate`` | ``auto`` (aggregate when ``staleness == 0``)."""
+    ``aggregate`` | ``auto`` (aggregate when ``staleness == 0`` and the workers own the shards).  ``cluster``: ps
+    tasks own the variables (see :class:`XpsCluster`); ``worker_index`` is then this worker's index and
+    ``defer_init`` lets a resuming chief restore a checkpoint before the ps tasks are initialised."""
 
     def __init__(self, model: nn.Module, *, optimizer: str = "adam", lr=1e-3, opt_kwargs: Optional[dict] = None,
                  staleness: int = -1, apply: str = "auto", grad_dtype: torch.dtype = torch.float32,
-                 timeout: float = 30.0, process_group=None):
+                 timeout: float = 30.0, process_group=None, cluster: Optional[XpsCluster] = None,
+                 worker_index: Optional[int] = None, defer_init: bool = False):
         self.model = model
         self.pg = process_group
-        self.distributed = dist.is_available() and dist.is_initialized()
-        self.world = dist.get_world_size(self.pg) if self.distributed else 1
-        self.rank = dist.get_rank(self.pg) if self.distributed else 0
-        if self.world > 8:
-            raise ValueError("the mailbox layout holds at most 8 ranks (one xGMI node)")
+        self.cluster = cluster
         self.mode = "async_ps"
         self.backend = "xgmi"
         self.staleness = int(staleness)
+        self.timeout = float(timeout)
+        if cluster is None:
+            self.distributed = dist.is_available() and dist.is_initialized()
+            self.nwrk = dist.get_world_size(self.pg) if self.distributed else 1
+            self.widx = dist.get_rank(self.pg) if self.distributed else 0
+            self.nown, self.oidx = self.nwrk, self.widx
+        else:
+            if worker_index is None:
+                raise ValueError("a worker of a ps cluster needs its worker_index")
+            self.distributed = False
+            self.nwrk, self.widx = int(cluster.num_workers), int(worker_index)
+            self.nown, self.oidx = int(cluster.num_ps), -1
+        self.world, self.rank = self.nwrk, self.widx
+        self.is_chief = self.widx == 0
+        if self.nown > MAX_OWNERS or self.nwrk > MAX_WORKERS:
+            raise ValueError("the region layout holds at most %d owners and %d workers (one xGMI node)"
+                             % (MAX_OWNERS, MAX_WORKERS))
         if apply == "auto":
-            apply = "aggregate" if self.staleness == 0 else "per_push"
+            apply = "aggregate" if (self.staleness == 0 and cluster is None) else "per_push"
         if apply not in ("per_push", "aggregate"):
             raise ValueError("apply must be per_push, aggregate or auto")
         if apply == "aggregate" and self.staleness != 0:
             raise ValueError("aggregated rounds are lock-step: they need staleness 0")
+        if apply == "aggregate" and cluster is not None:
+            raise ValueError("aggregated rounds need the workers to own the shards (no ps tasks)")
         self.apply = apply
-        self.timeout = float(timeout)
-        self.flat = FlatParams(model, bucket_mb=float(1 << 20), shard_multiple=self.world, grad_dtype=grad_dtype)
+        self.flat = FlatParams(model, bucket_mb=float(1 << 20), shard_multiple=self.nown, grad_dtype=grad_dtype)
         if self.flat.device.type != "cuda":
             raise ValueError("the xGMI parameter server keeps parameters in GPU memory; use --ps_backend=tcp on CPUs")
-        kw = dict(opt_kwargs or {})
         self.opt_name = optimizer.lower()
-        if self.opt_name == "adam":
-            self.kind, self.nslot = 0, 2
-            self.b1, self.b2, self.eps = kw.get("beta1", 0.9), kw.get("beta2", 0.999), kw.get("eps", 1e-8)
-            self.mu = self.wd = 0.0
-            self.nesterov = False
-        elif self.opt_name in ("momentum", "sgd"):
-            self.kind, self.nslot = 1, 1
-            self.b1 = self.b2 = self.eps = 0.0
-            self.mu, self.wd = kw.get("momentum", 0.9), kw.get("weight_decay", 0.0)
-            self.nesterov = bool(kw.get("nesterov", False))
-        else:
-            raise ValueError("unknown optimizer %r" % optimizer)
+        self.cfg = _opt_config(optimizer, opt_kwargs)
+        self.kind, self.nslot = self.cfg["kind"], self.cfg["nslot"]
         self.schedule: Schedule = lr if callable(lr) else constant(float(lr))
         self.optimizer = self  # the session asks ``engine.optimizer`` for current_lr / step_count
         self._steps = 0        # steps this worker has run
         self._base_step = 0    # global step at initialisation / restore
-        self.shards: List[_Shard] = []
-        with torch.cuda.device(self.flat.device):
-            for g in self.flat.groups:
-                gb = g.grad.dtype == torch.bfloat16
-                self.shards.append(_Shard(g, self.world, self.rank, self.nslot, gb, self.timeout, self.pg))
-            if self.distributed and self.world > 1:
-                # the chief's initial values everywhere (variables are initialised once, by the chief)
-                for g in self.flat.groups:
-                    dist.broadcast(g.master, 0, group=self.pg)
-                for b in model.buffers():
-                    if b.is_floating_point():
-                        dist.broadcast(b.data, 0, group=self.pg)
-            self._upload_own_shards(slots=None, applied=0)
-            torch.cuda.synchronize(self.flat.device)
-            if self.distributed and self.world > 1:
-                dist.barrier(group=self.pg)  # every shard is initialised and mapped before the first pull
-            self.pull()
+        self._stats_base: dict = {}
         self._closed = False
+        self._initialized = False
+        self._store = None
+        self.shards: List[_Region] = []
+        dev = self.flat.device
+        with torch.cuda.device(dev):
+            for g in self.flat.groups:
+                r = _Region(g.name, g.total, g.grad.dtype == torch.bfloat16, self.nown, self.nwrk, self.oidx, self.widx,
+                            self.nslot, self.timeout, dev)
+                r.group = g
+                self.shards.append(r)
+            if cluster is None:
+                self._connect_through_process_group()
+            else:
+                self._connect_through_store()
+            if not (defer_init and self.is_chief):
+                self.initialize()
+
+    # ------------------------------------------------------------------ start-up
+    def _connect_through_process_group(self) -> None:
+        for sh in self.shards:
+            mine = sh.handle()
+            handles = [None] * self.nown
+            if self.nown > 1:
+                dist.all_gather_object(handles, mine, group=self.pg)
+            else:
+                handles = [mine]
+            sh.connect(handles)
+        if self.distributed and self.nwrk > 1:
+            # the chief's initial values everywhere (variables are initialised once, by the chief)
+            for g in self.flat.groups:
+                dist.broadcast(g.master, 0, group=self.pg)
+            for b in self.model.buffers():
+                if b.is_floating_point():
+                    dist.broadcast(b.data, 0, group=self.pg)
+
+    def _connect_through_store(self) -> None:
+        store = self._store = self.cluster.store()
+        layout = json.dumps([{"name": sh.name, "total": sh.total, "grad_bf16": sh.group.grad.dtype == torch.bfloat16,
+                              "nslot": self.nslot, "decay": decay_spec(sh.group, 0, sh.group.total) is True}
+                             for sh in self.shards])
+        # every worker derives the same layout from the same model; the ps tasks allocate from the first one set
+        if store.add("xps/layout_set", 1) == 1:
+            store.set("xps/layout", layout)
+        else:
+            have = store.get("xps/layout").decode()
+            if json.loads(have) != json.loads(layout):
+                raise RuntimeError("this worker's parameter layout differs from the one the ps tasks were started with")
+        for gi, sh in enumerate(self.shards):
+            sh.connect([bytes(store.get("xps/%d/handle/%d" % (gi, o))) for o in range(self.nown)])
+
+    def initialize(self) -> None:
+        """Variables are initialised exactly once: the chief (or, without ps tasks, every owner for its own shard)
+        uploads the initial or restored values; everybody else waits for that.  Then the worker joins and pulls."""
+        if self._initialized:
+            return
+        dev = self.flat.device
+        with torch.cuda.device(dev):
+            if self.cluster is None:
+                self._upload_shards(slots=getattr(self, "_pending_slots", None), applied=self._base_step)
+                torch.cuda.synchronize(dev)
+                if self.distributed and self.nwrk > 1:
+                    dist.barrier(group=self.pg)  # every shard is initialised and mapped before the first pull
+            elif self.is_chief:
+                if self._store.add("xps/init_claim", 1) == 1:   # (a restarted chief finds the job initialised)
+                    self._upload_shards(slots=getattr(self, "_pending_slots", None), applied=self._base_step)
+                    torch.cuda.synchronize(dev)
+                    self._store.set("xps/ready", "1")
+                else:
+                    self._store.get("xps/ready")
+            else:
+                self._store.get("xps/ready")   # blocks until the chief has initialised the ps tasks
+            self._pending_slots = None
+            for sh in self.shards:
+                hipk.check(_lib().dtfa_xps_join(sh.ctx, self._st()), "xps_join")
+            self._initialized = True
+            self.pull()
+            torch.cuda.synchronize(dev)
+            self._base_step = int(self.shards[0].report()[0])
 
     # ------------------------------------------------------------------ helpers
     def _st(self) -> int:
         return torch.cuda.current_stream(self.flat.device).cuda_stream
 
-    def _own(self, t: torch.Tensor, sh: _Shard) -> torch.Tensor:
-        return t[self.rank * sh.piece:(self.rank + 1) * sh.piece]
+    def _piece(self, t: torch.Tensor, sh: _Region, o: int) -> torch.Tensor:
+        return t[o * sh.piece:(o + 1) * sh.piece]
 
-    def _upload_own_shards(self, slots: Optional[Dict[str, torch.Tensor]], applied: int) -> None:
-        """This rank's part of ``FlatGroup.master`` (and of full-layout optimizer slots) becomes the owner state."""
+    def _upload_shards(self, slots: Optional[Dict[str, torch.Tensor]], applied: int) -> None:
+        """``FlatGroup.master`` (and full-layout optimizer slots) become the owners' state: without ps tasks every
+        process uploads the shard it owns, with ps tasks the chief uploads all of them through the peer mappings."""
         L = _lib()
-        kinds = ["Adam", "Adam_1"] if self.kind == 0 else ["Momentum"]
+        owners = [self.oidx] if self.cluster is None else (list(range(self.nown)) if self.is_chief else [])
         for sh in self.shards:
             g = sh.group
-            sl = []
-            for k in kinds:
-                full = None if slots is None else slots.get(k + "/" + g.name)
-                sl.append(None if full is None else self._own(full.to(g.master.device, torch.float32), sh).contiguous())
-            while len(sl) < 2:
-                sl.append(None)
-            own = self._own(g.master, sh).contiguous()
-            hipk.check(L.dtfa_xps_set_shard(sh.ctx, own.data_ptr(), hipk.ptr(sl[0]), hipk.ptr(sl[1]), int(applied),
-                                            self._st()), "xps_set_shard")
+            for o in owners:
+                sl = []
+                for k in self.cfg["slots"]:
+                    full = None if slots is None else slots.get(k + "/" + g.name)
+                    sl.append(None if full is None else self._piece(full.to(g.master.device, torch.float32), sh, o).contiguous())
+                while len(sl) < 2:
+                    sl.append(None)
+                own = self._piece(g.master, sh, o).contiguous()
+                hipk.check(L.dtfa_xps_set_shard(sh.ctx, o, own.data_ptr(), hipk.ptr(sl[0]), hipk.ptr(sl[1]), int(applied),
+                                                self._st()), "xps_set_shard")
         self._base_step = int(applied)
+        self._steps = 0
 
     def current_lr(self) -> float:
         return self.schedule(self.global_step_estimate)
 
     @property
     def global_step_estimate(self) -> int:
-        """Host-side estimate used for the learning-rate schedule (no device synchronisation): lock-step rounds
-        count one global step per round, asynchronous applies one per push of every worker."""
-        per_step = 1 if self.apply == "aggregate" else self.world
-        return self._base_step + self._steps * per_step
+        """The global step the learning-rate schedule sees, without a device synchronisation.  Lock-step rounds: the
+        host counts them (one optimizer step per round, exact).  Asynchronous applies: the device-side count of
+        optimizer steps applied to shard 0, as of this worker's last pull -- it moves with what was really applied,
+        whatever the other workers' pace and however many of them are left."""
+        if self.apply == "aggregate":
+            return self._base_step + self._steps
+        return max(int(self.shards[0].report()[0]), self._base_step) if self.shards else self._base_step
 
     # ------------------------------------------------------------------ protocol
     def pull(self, into_master: bool = False) -> None:
@@ -214,7 +367,7 @@ class XgmiPSEngine:
         lr = self.schedule(self.global_step_estimate)
         if self.kind == 0 and self.apply == "aggregate":
             t = self.global_step_estimate + 1  # one optimizer step per round: the host knows its number
-            return lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+            return lr * math.sqrt(1.0 - self.cfg["b2"] ** t) / (1.0 - self.cfg["b1"] ** t)
         return lr
 
     def prepare_step(self) -> None:
@@ -229,6 +382,16 @@ class XgmiPSEngine:
     def graph_capturable(self) -> bool:
         return True
 
+    def _apply(self, sh: _Region, advance_clock: int, aggregate: bool) -> None:
+        c = self.cfg
+        wd = c["wd"] if decay_spec(sh.group, 0, sh.group.total) is True else 0.0
+        host_lr_t = int(self.kind == 0 and aggregate)
+        # regions of departed owner-workers are taken over by the lowest live one (only where workers own the shards)
+        adopt = int(self.cluster is None and self.nown > 1)
+        hipk.check(_lib().dtfa_xps_apply(sh.ctx, self.kind, c["b1"], c["b2"], c["eps"], c["mu"], wd, int(c["nesterov"]),
+                                         host_lr_t, int(aggregate), advance_clock, adopt, 0, 0.0, sh.hyper.data_ptr(),
+                                         self._st()), "xps_apply")
+
     def finish_step(self, prepared: bool = False) -> None:
         self.flat.collect_autograd_grads()
         from ..ops import functional as F
@@ -237,36 +400,25 @@ class XgmiPSEngine:
         if not prepared:
             self.prepare_step()
         L = _lib()
-        host_lr_t = int(self.kind == 0 and self.apply == "aggregate")
         for sh in self.shards:
             hipk.check(L.dtfa_xps_push(sh.ctx, sh.group.grad.data_ptr(), self._st()), "xps_push")
         for sh in self.shards:
-            wd = self.wd if decay_spec(sh.group, 0, sh.group.total) is True else 0.0
-            hipk.check(L.dtfa_xps_apply(sh.ctx, self.kind, self.b1, self.b2, self.eps, self.mu, wd, int(self.nesterov),
-                                        host_lr_t, int(self.apply == "aggregate"), 1, sh.hyper.data_ptr(), self._st()),
-                       "xps_apply")
+            self._apply(sh, 1, self.apply == "aggregate")
         if not prepared:
             self.advance_step()
 
     def drain(self) -> None:
         """Owner: apply what has arrived without taking a worker step (e.g. before a checkpoint or at the end)."""
-        if self.apply == "aggregate":
+        if self.apply == "aggregate" or self.oidx < 0:
             return
-        L = _lib()
         self.prepare_step()
         for sh in self.shards:
-            wd = self.wd if decay_spec(sh.group, 0, sh.group.total) is True else 0.0
-            hipk.check(L.dtfa_xps_apply(sh.ctx, self.kind, self.b1, self.b2, self.eps, self.mu, wd, int(self.nesterov), 0, 0, 0,
-                                        sh.hyper.data_ptr(), self._st()), "xps_apply")
+            self._apply(sh, 0, False)
 
     # ------------------------------------------------------------------ state
     def state(self) -> dict:
-        """Counters of the first group's region (synchronises the stream)."""
-        out = (C.c_uint * 24)()
-        hipk.check(_lib().dtfa_xps_state(self.shards[0].ctx, out, self._st()), "xps_state")
-        return {"clock": out[0], "version": out[1], "applied": out[2], "global_step": out[3], "status": out[4],
-                "torn_pulls": out[5], "dropped_pushes": out[6], "timeouts": out[7], "dead_mask": out[8],
-                "pushes": out[9], "done_mask": out[10], "clocks": [out[16 + r] for r in range(self.world)]}
+        """Counters of the first group's regions (synchronises the stream)."""
+        return self.shards[0].state(self._st(), self.nown, self.nwrk)
 
     # -- communication accounting (same interface as DataParallelEngine; bench.py reports it) ----------------
     measure_comm = False
@@ -276,28 +428,35 @@ class XgmiPSEngine:
 
     def comm_stats(self) -> dict:
         """Protocol counters since :meth:`reset_comm_stats` (synchronises the stream): what was pushed, what was
-        dropped or torn, which peers were written off."""
+        dropped or torn, which peers were written off, which regions this process took over."""
         st = self.state()
-        base = getattr(self, "_stats_base", None) or {}
+        base = self._stats_base or {}
         gbytes = sum(sh.group.grad.numel() * sh.group.grad.element_size() for sh in self.shards)
         pbytes = sum(sh.group.total * 4 for sh in self.shards)
 
         def since(k):
             return int(st[k]) - int(base.get(k, 0))
 
-        return {"collective": False, "world": self.world, "mode": self.mode, "backend": self.backend,
+        return {"collective": False, "world": self.nwrk, "owners": self.nown, "mode": self.mode, "backend": self.backend,
+                "owned_by": "ps tasks" if self.cluster is not None else "workers",
                 "apply": self.apply, "staleness": self.staleness,
                 "grad_dtype": str(self.shards[0].group.grad.dtype).replace("torch.", "") if self.shards else None,
                 "groups": len(self.shards), "pushed_bytes_per_step": int(gbytes), "pulled_bytes_per_step": int(pbytes),
-                "pushes": since("pushes"), "applied": since("applied"), "status": int(st["status"]),
+                "pushes": since("pushes"), "applied": since("global_step"), "status": int(st["status"]),
                 "dropped_pushes": since("dropped_pushes"), "torn_pulls": since("torn_pulls"),
                 "timeouts": since("timeouts"), "dead_mask": int(st["dead_mask"]), "done_mask": int(st["done_mask"]),
+                "adopted_mask": int(st["adopted_mask"]), "applied_per_shard": st["applied_per_shard"],
                 "clocks": st["clocks"]}
 
     @property
     def global_step(self) -> int:
-        """Optimizer steps applied to shard 0 (the analogue of ``global_step`` living on ps task 0)."""
-        return int(self.state()["global_step"])
+        """Optimizer steps applied to the variables: the largest count over the shards (every push reaches every
+        shard, so the counts differ only by what is in flight, and a departed chief or owner does not freeze it).
+        Read from the words the kernels report; no device synchronisation."""
+        if self.apply == "aggregate":
+            return self._base_step + self._steps
+        a0, _, own = self.shards[0].report()
+        return max(int(a0), int(own), self._base_step)
 
     @property
     def step_count(self) -> int:
@@ -315,43 +474,47 @@ class XgmiPSEngine:
 
     def full_slots(self) -> Dict[str, torch.Tensor]:
         L = _lib()
-        kinds = ["Adam", "Adam_1"] if self.kind == 0 else ["Momentum"]
         out = {}
         for sh in self.shards:
             g = sh.group
-            for k, kind in enumerate(kinds):
+            for k, kind in enumerate(self.cfg["slots"]):
                 full = torch.zeros(g.total, dtype=torch.float32, device=g.master.device)
-                for o in range(self.world):
+                for o in range(self.nown):
                     hipk.check(L.dtfa_xps_read_slot(sh.ctx, o, k, full[o * sh.piece:].data_ptr(), self._st()), "xps_read_slot")
                 out[kind + "/" + g.name] = full
         return out
 
     @property
     def fetched_global_step(self) -> Optional[int]:
-        return self.global_step
+        return int(self.state()["global_step"])
 
     @property
     def beta1_power(self):
-        return self.b1 ** (self.global_step + 1) if self.kind == 0 else None
+        return self.cfg["b1"] ** (self.fetched_global_step + 1) if self.kind == 0 else None
 
     @property
     def beta2_power(self):
-        return self.b2 ** (self.global_step + 1) if self.kind == 0 else None
+        return self.cfg["b2"] ** (self.fetched_global_step + 1) if self.kind == 0 else None
 
     def load_master(self) -> None:
-        """After a restore wrote ``FlatGroup.master`` (every rank loads the checkpoint): each owner re-publishes its
-        own shard with the restored step count; slots follow in :meth:`load_full_slots`."""
-        self._pending_restore = True
-        self._upload_own_shards(slots=None, applied=self._base_step)
+        """After a restore wrote ``FlatGroup.master``: the owners' shards are re-published with the restored step
+        count (without ps tasks every rank loads the checkpoint and uploads its own shard; with ps tasks the chief
+        uploads all of them); slots follow in :meth:`load_full_slots`."""
+        if not self._initialized:
+            return   # (a resuming chief: the restored values are uploaded by initialize())
+        self._upload_shards(slots=None, applied=self._base_step)
         self._resync()
 
     def load_full_slots(self, full: Dict[str, torch.Tensor]) -> None:
-        self._upload_own_shards(slots=full, applied=self._base_step)
+        if not self._initialized:
+            self._pending_slots = {k: v.detach().clone() for k, v in full.items()}
+            return
+        self._upload_shards(slots=full, applied=self._base_step)
         self._resync()
 
     def _resync(self) -> None:
         torch.cuda.current_stream(self.flat.device).synchronize()
-        if self.distributed and self.world > 1:
+        if self.distributed and self.nwrk > 1:
             dist.barrier(group=self.pg)
         self.pull()
 
@@ -362,5 +525,73 @@ class XgmiPSEngine:
         L = _lib()
         for sh in self.shards:
             hipk.check(L.dtfa_xps_leave(sh.ctx, self._st()), "xps_leave")
+            if shutdown_ps and self.cluster is not None:
+                hipk.check(L.dtfa_xps_shutdown(sh.ctx, self._st()), "xps_shutdown")
         torch.cuda.current_stream(self.flat.device).synchronize()
-        # the regions stay allocated until the process exits: peers may still be reading them
+        # the regions stay allocated until the process exits: peers may still be reading them, and the process
+        # that takes a departed owner's region over keeps applying it in place
+
+
+class XgmiPSServer:
+    """One ps task of the xGMI parameter server: owns shard ``ps_index`` of every flat group and applies the
+    gradients that arrive in its mailboxes until the chief asks it to stop (the counterpart of ``server.join()``,
+    recognition_flower/distributed/train_dataset.py:142-145).  ps task 0 also hosts the rendezvous store.  The
+    layout (group sizes, gradient dtype) is taken from the store, where the first worker publishes it, so a ps task
+    never builds the model."""
+
+    def __init__(self, cluster: XpsCluster, ps_index: int, *, optimizer: str = "adam", lr=1e-3,
+                 opt_kwargs: Optional[dict] = None, timeout: float = 30.0, device=None, idle_seconds: float = 0.02):
+        self.cluster = cluster
+        self.ps_index = int(ps_index)
+        self.cfg = _opt_config(optimizer, opt_kwargs)
+        self.schedule: Schedule = lr if callable(lr) else constant(float(lr))
+        self.timeout = float(timeout)
+        self.idle = float(idle_seconds)
+        self.device = torch.device(device if device is not None else "cuda")
+        self.store = cluster.store(is_master=(self.ps_index == 0))
+        self.regions: List[_Region] = []
+        self.applied = 0
+
+    def _allocate(self) -> None:
+        layout = json.loads(self.store.get("xps/layout").decode())
+        n, w = self.cluster.num_ps, self.cluster.num_workers
+        with torch.cuda.device(self.device):
+            for gi, g in enumerate(layout):
+                if int(g["nslot"]) != self.cfg["nslot"]:
+                    raise RuntimeError("the workers run optimizer slots %d, this ps task %d" % (g["nslot"], self.cfg["nslot"]))
+                r = _Region(g["name"], g["total"], bool(g["grad_bf16"]), n, w, self.ps_index, -1, self.cfg["nslot"],
+                            self.timeout, self.device)
+                r.no_decay_all = not g.get("decay", True)   # (a group of 1-D parameters: batch-norm scales, biases)
+                self.regions.append(r)
+                self.store.set("xps/%d/handle/%d" % (gi, self.ps_index), r.handle())
+            for gi, r in enumerate(self.regions):
+                r.connect([bytes(self.store.get("xps/%d/handle/%d" % (gi, o))) for o in range(n)])
+
+    def serve_forever(self, poll_seconds: float = 0.25) -> int:
+        """Returns the number of optimizer steps applied to this task's shard of the first group."""
+        self._allocate()
+        L = _lib()
+        c = self.cfg
+        n, w = self.cluster.num_ps, self.cluster.num_workers
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            last_poll = 0.0
+            while True:
+                lr = self.schedule(self.applied)
+                for r in self.regions:
+                    hipk.check(hipk.lib().dtfa_set_hyper(r.hyper.data_ptr(), float(lr), 1.0, st), "set_hyper")
+                    wd = 0.0 if r.no_decay_all else c["wd"]
+                    # (the collect kernel sleeps up to ``idle`` seconds on the device until a gradient has arrived)
+                    hipk.check(L.dtfa_xps_apply(r.ctx, c["kind"], c["b1"], c["b2"], c["eps"], c["mu"], wd, int(c["nesterov"]),
+                                                0, 0, 0, 0, 1, self.idle, r.hyper.data_ptr(), st), "xps_apply")
+                torch.cuda.current_stream(self.device).synchronize()
+                self.applied = int(self.regions[0].report()[2])
+                now = time.monotonic()
+                if now - last_poll >= poll_seconds:
+                    last_poll = now
+                    s = self.regions[0].state(st, n, w)
+                    joined, done = s["joined_mask"], s["done_mask"]
+                    if s["shutdown"] or (joined and (joined & ~done) == 0 and s["arrived"] == s["consumed"]):
+                        # asked to stop, or every worker that ever joined has left and nothing is waiting
+                        break
+        return self.applied

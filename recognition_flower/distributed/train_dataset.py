@@ -34,6 +34,7 @@ import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for peer-mapped GPU memory (RCCL, xGMI mailboxes)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for peer-mapped GPU memory (RCCL, xGMI mailboxes)
 
 import torch  # noqa: E402
 
@@ -132,15 +133,51 @@ def train_input_fn(tfrecords_path, params, device, rank, world, channels=8):
                        channels=channels)
 
 
+def _optimizer_config():
+    """(optimizer name, its keyword arguments, learning rate or schedule) from the flags; the same on every task."""
+    name = FLAGS.optimizer.lower()
+    kwargs = {"momentum": FLAGS.momentum, "weight_decay": FLAGS.weight_decay} if name == "momentum" else {}
+    rate = params["learning_rate"]
+    if FLAGS.lr_decay_steps > 0:
+        from distributed_tensorflow_amd.optim.schedules import exponential_decay
+
+        rate = exponential_decay(rate, FLAGS.lr_decay_steps, FLAGS.lr_decay_rate)
+    return name, kwargs, rate
+
+
+def _xps_cluster(spec):
+    """ps tasks own the variables in GPU memory: ps task 0's address is where the rendezvous store lives."""
+    from distributed_tensorflow_amd.parallel.xps import XpsCluster
+
+    host, port = spec.address("ps", 0)
+    return XpsCluster("127.0.0.1" if host == "localhost" else host, port, len(spec.ps_hosts), spec.num_workers)
+
+
 def run_ps(spec):
     from distributed_tensorflow_amd.parallel.ps import ParameterServer
 
-    if FLAGS.mode != "async_ps" or FLAGS.ps_backend == "xgmi":
-        print("ps task %d: mode %s%s keeps parameters on the workers; nothing to serve" % (
-            spec.task_index, FLAGS.mode, " (xgmi)" if FLAGS.mode == "async_ps" else ""))
+    if FLAGS.mode != "async_ps":
+        print("ps task %d: mode %s keeps parameters on the workers; nothing to serve" % (spec.task_index, FLAGS.mode))
         return 0
     if FLAGS.wipe_checkpoint_dir and spec.task_index == 0 and os.path.exists(FLAGS.checkpoint_dir):
         shutil.rmtree(FLAGS.checkpoint_dir)
+    if FLAGS.ps_backend == "xgmi":
+        # the ps task owns its shard of the variables and their optimizer slots in GPU memory and applies the
+        # gradients the workers push into its mailboxes (the reference's ps: train_dataset.py:141-145)
+        from distributed_tensorflow_amd.parallel.xps import XgmiPSServer
+        from distributed_tensorflow_amd.utils.cluster import local_device_index
+
+        if not torch.cuda.is_available():
+            raise ValueError("--ps_backend=xgmi keeps the variables in GPU memory")
+        idx = local_device_index(spec.num_workers + spec.task_index, torch.cuda.device_count()) or 0
+        torch.cuda.set_device(idx)
+        opt_name, opt_kwargs, lr = _optimizer_config()
+        server = XgmiPSServer(_xps_cluster(spec), spec.task_index, optimizer=opt_name, lr=lr, opt_kwargs=opt_kwargs,
+                              timeout=FLAGS.worker_timeout, device=torch.device("cuda", idx))
+        print("ps %d owning shard %d of %d on GPU %d" % (spec.task_index, spec.task_index, len(spec.ps_hosts), idx), flush=True)
+        applied = server.serve_forever()
+        print("ps %d stopped after %d optimizer steps" % (spec.task_index, applied))
+        return 0
     host, port = spec.my_address()
     server = ParameterServer("0.0.0.0" if host not in ("localhost", "127.0.0.1") else "127.0.0.1", port,
                              ps_index=spec.task_index, staleness=FLAGS.staleness, worker_timeout=FLAGS.worker_timeout)
@@ -195,15 +232,8 @@ def run_worker(spec):
             if isinstance(m, ConvBnAct):
                 m.momentum = 1.0 - FLAGS.bn_decay
 
-    opt_name = FLAGS.optimizer.lower()
-    opt_kwargs = {"momentum": FLAGS.momentum, "weight_decay": FLAGS.weight_decay} if opt_name == "momentum" else {}
+    opt_name, opt_kwargs, lr_schedule = _optimizer_config()
     lr = params["learning_rate"]
-    if FLAGS.lr_decay_steps > 0:
-        from distributed_tensorflow_amd.optim.schedules import exponential_decay
-
-        lr_schedule = exponential_decay(lr, FLAGS.lr_decay_steps, FLAGS.lr_decay_rate)
-    else:
-        lr_schedule = lr
     xgmi = FLAGS.mode == "async_ps" and FLAGS.ps_backend == "xgmi"
     if xgmi:
         import datetime
@@ -213,25 +243,33 @@ def run_worker(spec):
 
         if device.type != "cuda":
             raise ValueError("--ps_backend=xgmi keeps the variables in GPU memory")
-        if world > 1 and not dist.is_initialized():
-            if tr is None:
-                os.environ.update(rendezvous_from_cluster(spec))
-            # the process group only carries the IPC handles and the chief's initial values at start-up
-            dist.init_process_group("gloo", rank=task_index, world_size=world,
-                                    timeout=datetime.timedelta(seconds=FLAGS.collective_timeout))
         grad_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[FLAGS.grad_dtype]
-        engine = XgmiPSEngine(model, optimizer=opt_name, lr=lr_schedule, opt_kwargs=opt_kwargs, staleness=FLAGS.staleness,
-                              apply=FLAGS.ps_apply, grad_dtype=grad_dtype, timeout=FLAGS.worker_timeout)
+        if spec.ps_hosts:
+            # the reference's topology: the ps tasks own the variables, this worker is a pure client of their
+            # GPU memory and may start late or die without taking anything with it
+            engine = XgmiPSEngine(model, optimizer=opt_name, lr=lr_schedule, opt_kwargs=opt_kwargs, staleness=FLAGS.staleness,
+                                  apply=FLAGS.ps_apply, grad_dtype=grad_dtype, timeout=FLAGS.worker_timeout,
+                                  cluster=_xps_cluster(spec), worker_index=task_index,
+                                  defer_init=FLAGS.resume and is_chief)
+        else:
+            if world > 1 and not dist.is_initialized():
+                if tr is None:
+                    os.environ.update(rendezvous_from_cluster(spec))
+                # the process group only carries the IPC handles and the chief's initial values at start-up
+                dist.init_process_group("gloo", rank=task_index, world_size=world,
+                                        timeout=datetime.timedelta(seconds=FLAGS.collective_timeout))
+            # no ps tasks: every worker GPU owns 1/N of the variables
+            engine = XgmiPSEngine(model, optimizer=opt_name, lr=lr_schedule, opt_kwargs=opt_kwargs, staleness=FLAGS.staleness,
+                                  apply=FLAGS.ps_apply, grad_dtype=grad_dtype, timeout=FLAGS.worker_timeout)
     elif FLAGS.mode == "async_ps" and spec.ps_hosts:
         from distributed_tensorflow_amd.parallel.ps import PSWorkerEngine
 
-        if FLAGS.lr_decay_steps > 0:
-            raise ValueError("--lr_decay_steps needs a collective mode: the ps tasks apply a constant rate")
         ps_addr = [spec.address("ps", i) for i in range(len(spec.ps_hosts))]
         ps_addr = [("127.0.0.1" if h == "localhost" else h, p) for h, p in ps_addr]
         # a resuming chief restores the checkpoint first and initialises the ps tasks from it
         engine = PSWorkerEngine(model, ps_addr, task_index, is_chief, optimizer=opt_name, lr=lr, opt_kwargs=opt_kwargs,
-                                defer_init=FLAGS.resume and is_chief)
+                                defer_init=FLAGS.resume and is_chief,
+                                lr_decay=(FLAGS.lr_decay_steps, FLAGS.lr_decay_rate) if FLAGS.lr_decay_steps > 0 else None)
     else:
         import torch.distributed as dist
         from distributed_tensorflow_amd.parallel.engine import DataParallelEngine
@@ -251,7 +289,7 @@ def run_worker(spec):
     saver = Saver(model, engine)
     start_step = 0
     # async_ps: the chief restores and uploads to the ps tasks; collective modes: every rank loads the file
-    collective = xgmi or not (FLAGS.mode == "async_ps" and spec.ps_hosts)
+    collective = not (FLAGS.mode == "async_ps" and spec.ps_hosts)
     if FLAGS.resume and (is_chief or collective):
         restored = saver.restore_latest(FLAGS.checkpoint_dir)
         if restored is not None:

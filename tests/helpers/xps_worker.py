@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from distributed_tensorflow_amd.models import build_model  # noqa: E402
 from distributed_tensorflow_amd.ops import functional as F  # noqa: E402
 from distributed_tensorflow_amd.parallel.engine import DataParallelEngine  # noqa: E402
-from distributed_tensorflow_amd.parallel.xps import XgmiPSEngine  # noqa: E402
+from distributed_tensorflow_amd.parallel.xps import XgmiPSEngine, XgmiPSServer, XpsCluster  # noqa: E402
 
 WIDTHS = (8, 8, 16, 16, 16)
 
@@ -43,8 +43,61 @@ def masters(eng):
     return torch.cat([g.master[s.offset:s.offset + s.numel].clone().cpu() for g in eng.flat.groups for s in g.segments])
 
 
+def ps_cluster_role(rank, world, port, mode, out_dir):
+    """ps tasks own the variables: process 0 and 1 are ps tasks, the others workers 0 .. world - 3.  Worker 1 dies
+    after two steps without a word; the last worker starts when the others are well under way."""
+    torch.cuda.set_device(0)
+    n_ps, n_workers = 2, world - 2
+    cluster = XpsCluster("127.0.0.1", int(port), n_ps, n_workers, connect_timeout=60.0)
+    result = {"rank": rank}
+    if rank < n_ps:
+        server = XgmiPSServer(cluster, rank, optimizer="adam", lr=1e-2, timeout=2.0)
+        applied = server.serve_forever()
+        result.update(role="ps", applied=applied)
+        assert applied > 0
+    else:
+        w = rank - n_ps
+        late = w == n_workers - 1
+        if late:
+            time.sleep(4.0)
+        m = model()
+        if w != 0:
+            with torch.no_grad():   # only the chief's initial values may survive
+                for p in m.parameters():
+                    p.add_(1.0)
+        eng = XgmiPSEngine(m, optimizer="adam", lr=1e-2, staleness=2, timeout=2.0, cluster=cluster, worker_index=w)
+        joined_at = eng.global_step
+        if late:
+            # a worker that joins at step k starts from the values of step k, not from the initial ones
+            assert joined_at > 0, joined_at
+        losses = []
+        steps = 6 if late else 14
+        for t in range(steps):
+            if w == 1 and t == 2:
+                print("XPS_DYING worker", w, flush=True)
+                os._exit(0)
+            if not late:
+                time.sleep(0.5)
+            losses.append(float(step(m, eng, 0, 0).item()))   # one fixed batch: the loss must fall
+            torch.cuda.synchronize()
+        st = eng.state()
+        result.update(role="worker", worker=w, joined_at=int(joined_at), losses=losses, state=st)
+        assert st["dropped_pushes"] == 0 and st["torn_pulls"] == 0, st
+        assert losses[-1] < losses[0], losses
+        if w == 0:
+            time.sleep(1.0)   # (the late worker's last pushes reach the ps tasks before they are asked to stop)
+            st = eng.state()
+            # every push of every worker was applied to every shard: 14 (chief) + 2 (the dead one) + 6 (the late one)
+            assert min(st["applied_per_shard"]) >= 14 + 2, st
+        eng.close(shutdown_ps=(w == 0))
+    print("XPS_OK " + json.dumps(result), flush=True)
+    os._exit(0)
+
+
 def main():
     rank, world, port, mode, out_dir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    if mode == "ps_owned":
+        return ps_cluster_role(rank, world, port, mode, out_dir)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
     torch.cuda.set_device(0)
     opt = "momentum" if "momentum" in mode else "adam"
@@ -110,24 +163,36 @@ def main():
         eng.close()
     elif mode == "dead":
         # one worker dies after two steps without saying goodbye; the others finish their steps, paying the
-        # timeout once
+        # timeout once, and the lowest live rank takes the dead worker's shard over: it keeps being applied
         m = model()
-        eng = XgmiPSEngine(m, optimizer="adam", lr=1e-3, staleness=1, timeout=1.5)
-        t_steps = []
-        for t in range(7):
+        eng = XgmiPSEngine(m, optimizer="adam", lr=1e-2, staleness=1, timeout=1.5)
+        t_steps, losses, applied_mid = [], [], None
+        for t in range(12):
             if rank == world - 1 and t == 2:
                 print("XPS_DYING rank", rank, flush=True)
                 os._exit(0)
             t0 = time.time()
-            step(m, eng, rank, t)
+            losses.append(float(step(m, eng, 0, 0).item()))   # one fixed batch for everybody: the loss must keep falling
             torch.cuda.synchronize()
             t_steps.append(time.time() - t0)
+            if t == 6:
+                applied_mid = eng.state()["applied_per_shard"]
+        torch.cuda.synchronize()
+        time.sleep(0.5)
+        eng.drain()
         st = eng.state()
-        result.update(step_seconds=t_steps, state=st)
-        assert st["clock"] == 7, st
+        result.update(step_seconds=t_steps, state=st, losses=losses, applied_mid=applied_mid)
+        assert st["clock"] == 12, st
         assert st["dead_mask"] == 1 << (world - 1), st
         slow = [x for x in t_steps if x > 1.0]
-        assert len(slow) <= 2, t_steps  # the gate (and at most one slot wait) ran into the timeout once
+        assert len(slow) <= 3, t_steps  # the gate and the full mailbox slot of the dead owner ran into the timeout once each
+        # the dead worker's shard was taken over by rank 0 and kept training like the others
+        assert st["adopters"][world - 1] == 1, st
+        assert (st["adopted_mask"] != 0) == (rank == 0), st
+        for o in range(world):
+            assert st["applied_per_shard"][o] > applied_mid[o] > 2, (o, applied_mid, st)
+        assert min(st["applied_per_shard"]) >= 2 * 9, st     # two live workers x the steps after the take-over
+        assert losses[-1] < 0.5 * losses[0], losses
         eng.close()
     elif mode == "ckpt":
         # checkpoint through the Saver: masters and slots gathered by one-sided reads, restored into a new engine

@@ -151,27 +151,61 @@ def test_model_server_on_gpu_matches_servable(tmp_path):
     finally:
         server.stop()
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 @pytest.mark.gpu
 def test_xgmi_parameter_server_via_tf_config_roles(tmp_path):
     """The reference's launch (TF_CONFIG roles: one ps task, two workers; run.sh) with --ps_backend=xgmi: the ps task
-    has nothing to serve and exits, the workers own the variables in GPU memory and exchange gradients and values
-    through peer-mapped mailboxes (here both on the one GPU of the box), the chief writes the checkpoint."""
-    import socket
-
-    def port():
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
-
-    cluster = {"ps": ["localhost:%d" % port()], "worker": ["localhost:%d" % port(), "localhost:%d" % port()]}
+    owns the variables and their Adam slots in GPU memory and applies what the workers push into its mailboxes, the
+    workers are clients of that memory (here all on the one GPU of the box), the learning rate decays on the ps
+    task's own step count, the chief writes the checkpoint and stops the ps task when the step budget is used up."""
+    cluster = {"ps": ["localhost:%d" % _free_port()], "worker": ["localhost:%d" % _free_port(), "localhost:%d" % _free_port()]}
     common = ["train_dataset.py", "--synthetic", "--model=flower_cnn", "--image_size=64", "--batch_size=8",
               "--train_steps=12", "--mode=async_ps", "--ps_backend=xgmi", "--staleness=1", "--device=cuda",
-              "--checkpoint_dir=%s/ckpt/" % tmp_path, "--summaries_dir=%s/events/" % tmp_path]
+              "--lr_decay_steps=4", "--checkpoint_dir=%s/ckpt/" % tmp_path, "--summaries_dir=%s/events/" % tmp_path]
     procs = []
     for task in ({"type": "ps", "index": 0}, {"type": "worker", "index": 0}, {"type": "worker", "index": 1}):
-        env = dict(os.environ, TF_CONFIG=json.dumps({"cluster": cluster, "task": task}), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}   # the entry point sets it
+        env["TF_CONFIG"] = json.dumps({"cluster": cluster, "task": task})
         procs.append(subprocess.Popen([sys.executable] + common, cwd=DIST, env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert [p.returncode for p in procs] == [0, 0, 0], outs
-    assert "nothing to serve" in outs[0]
+    assert "owning shard 0 of 1" in outs[0] and "stopped after" in outs[0]
+    applied = int(outs[0].split("stopped after")[1].split()[0])
+    assert applied >= 12
     assert "finished training (worker 0" in outs[1] and "finished training (worker 1" in outs[2]
     assert int(bundle.read_bundle(bundle.latest_checkpoint(str(tmp_path / "ckpt")))["global_step"]) >= 12
+
+
+@pytest.mark.gpu
+def test_xgmi_parameter_server_without_ps_tasks_resumes(tmp_path):
+    """TF_CONFIG with workers only and --ps_backend=xgmi: every worker GPU owns half of the variables; a second run
+    with --resume continues from the first run's checkpoint."""
+    def run(steps, resume):
+        cluster = {"worker": ["localhost:%d" % _free_port(), "localhost:%d" % _free_port()]}
+        common = ["train_dataset.py", "--synthetic", "--model=flower_cnn", "--image_size=64", "--batch_size=8",
+                  "--train_steps=%d" % steps, "--mode=async_ps", "--ps_backend=xgmi", "--staleness=0", "--device=cuda",
+                  "--checkpoint_dir=%s/ckpt/" % tmp_path, "--summaries_dir=%s/events/" % tmp_path] + (["--resume"] if resume else [])
+        procs = []
+        for i in range(2):
+            env = dict(os.environ, TF_CONFIG=json.dumps({"cluster": cluster, "task": {"type": "worker", "index": i}}))
+            procs.append(subprocess.Popen([sys.executable] + common, cwd=DIST, env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=240)[0] for p in procs]
+        assert [p.returncode for p in procs] == [0, 0], outs
+        return outs
+
+    run(6, False)
+    assert int(bundle.read_bundle(bundle.latest_checkpoint(str(tmp_path / "ckpt")))["global_step"]) >= 6
+    outs = run(10, True)
+    assert "resumed from global step" in outs[0]
+    assert int(bundle.read_bundle(bundle.latest_checkpoint(str(tmp_path / "ckpt")))["global_step"]) >= 10

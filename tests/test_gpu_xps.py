@@ -62,10 +62,21 @@ def test_staleness_bound_holds_and_every_push_is_applied_once(tmp_path):
     _ok(procs, outs)
 
 
-def test_dead_worker_does_not_stall_the_others(tmp_path):
+def test_dead_workers_shard_is_taken_over_and_keeps_training(tmp_path):
+    """No ps tasks (every worker owns a shard): a worker that dies delays the others by a timeout, once; the lowest
+    live rank then applies the dead worker's shard in place, so no variable stops training."""
     procs, outs = _launch("dead", 3, tmp_path)
     assert "XPS_DYING" in outs[2]
     _ok(procs, outs, ranks=(0, 1))
+
+
+def test_ps_tasks_own_the_variables_workers_die_and_join_late(tmp_path):
+    """The reference's topology: two ps processes own the shards and only apply, three workers are clients of their
+    memory.  One worker dies (nothing is lost: no push dropped, both shards keep counting), one joins when the job
+    is well under way and pulls the current values, the chief stops the ps tasks at the end."""
+    procs, outs = _launch("ps_owned", 5, tmp_path)
+    assert "XPS_DYING" in outs[3]
+    _ok(procs, outs, ranks=(0, 1, 2, 4))
 
 
 def test_checkpoint_and_restore_through_one_sided_reads(tmp_path):

@@ -106,6 +106,31 @@ def test_ps_applies_tf1_adam_and_counts_global_steps(servers):
     eng.close()
 
 
+def test_learning_rate_decay_runs_on_the_ps(servers):
+    """``lr_decay`` travels to the ps tasks with the initialisation: their optimizer steps follow
+    ``lr * rate ** (global_step / decay_steps)`` exactly like a local optimizer with the same schedule."""
+    from distributed_tensorflow_amd.optim.schedules import exponential_decay
+    from distributed_tensorflow_amd.parallel.engine import DataParallelEngine
+
+    (ps, addr), = servers(1)
+    model = _model(1)
+    eng = PSWorkerEngine(model, [addr], 0, True, optimizer="adam", lr=1e-2, lr_decay=(2, 0.5))
+    ref = _model(1)
+    ref_eng = DataParallelEngine(ref, mode="sync_dp", optimizer="adam", lr=exponential_decay(1e-2, 2, 0.5), bucket_mb=1 << 20)
+    for t in range(4):
+        _step(model, eng, t)
+        ref_eng.begin_step()
+        logits, reg = ref(_batch(t)[0])
+        loss, _, _, _ = F.softmax_xent(logits, _batch(t)[1], 5)
+        (loss + reg).backward()
+        ref_eng.finish_step()
+    eng.pull()
+    for (n, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=n)
+    assert abs(eng.current_lr() - 1e-2 * 0.5 ** 2) < 1e-9
+    eng.close()
+
+
 def test_variables_are_placed_round_robin_over_ps_tasks(servers):
     pair = servers(2)
     addrs = [a for _, a in pair]
