@@ -161,26 +161,30 @@ __global__ __launch_bounds__(64) void xps_gate_kernel(XpsPtrs P, XpsPriv* pv, in
 }
 
 // ---------------------------------------------------------------------------------------------------- pull
-// dst (compute dtype) and / or dst32 (fp32) receive nown * piece values: shard o from region o's current version.
+// dst (compute dtype) and / or dst32 (fp32) receive the group's values [lo, hi) (element indices in the group, whole
+// 16-byte vectors): every shard's part of that range from its region's current version.
 template <bool BF16>
 __global__ __launch_bounds__(256) void xps_pull_kernel(XpsPtrs P, XpsPriv* pv, int nown, size_t piece, size_t off_params,
                                                        void* __restrict__ dst, float* __restrict__ dst32,
-                                                       unsigned blocks_per_owner, XpsReport* report) {
+                                                       unsigned blocks_per_owner, XpsReport* report, size_t lo, size_t hi) {
   const int o = blockIdx.x / blocks_per_owner;
   const unsigned b = blockIdx.x % blocks_per_owner;
   if (o >= nown) return;
   const XpsCtrl* c = ctrl_of(P, o);
   if (blockIdx.x == 0 && threadIdx.x == 0) st_sys(&report->applied0, ld_sys(&c->applied));
-  const size_t nvec = piece / 4;
+  const size_t o_lo = (size_t)o * piece, o_hi = o_lo + piece;
+  const size_t a = lo > o_lo ? lo : o_lo, z = hi < o_hi ? hi : o_hi;
+  if (a >= z) return;
+  const size_t v0 = (a - o_lo) / 4, v1 = (z - o_lo) / 4;   // this shard's vectors [v0, v1)
   __shared__ unsigned sv;
   for (int attempt = 0; attempt < 4; ++attempt) {
     if (threadIdx.x == 0) sv = ld_sys(&c->version);
     __syncthreads();
     const unsigned v = sv;
     const float* src = (const float*)(P.base[o] + off_params) + (size_t)(v & 1u) * piece;
-    for (size_t i = (size_t)b * blockDim.x + threadIdx.x; i < nvec; i += (size_t)blocks_per_owner * blockDim.x) {
+    for (size_t i = v0 + (size_t)b * blockDim.x + threadIdx.x; i < v1; i += (size_t)blocks_per_owner * blockDim.x) {
       const f32x4 w = __builtin_nontemporal_load((const f32x4*)(src + i * 4));
-      const size_t e = (size_t)o * piece + i * 4;
+      const size_t e = o_lo + i * 4;
       if (dst32) *(f32x4*)(dst32 + e) = w;
       if (dst) {
         if (BF16) {
@@ -662,19 +666,30 @@ static unsigned blocks_per_owner(size_t piece, int nown) {
   return (unsigned)(b ? b : 1);
 }
 
-// dst: nown * piece values of the compute dtype (may be null); dst32: the same in fp32 (may be null).
-extern "C" int dtfa_xps_pull(void* ctx, void* dst, int dst_is_bf16, float* dst32, hipStream_t st) {
+// dst: the group's nown * piece values in the compute dtype (may be null); dst32: the same in fp32 (may be null).
+// Only the elements [lo, hi) are refreshed (multiples of 4; hi <= 0: up to the end).
+extern "C" int dtfa_xps_pull_range(void* ctx, void* dst, int dst_is_bf16, float* dst32, long long lo, long long hi,
+                                   hipStream_t st) {
   XpsCtx* c = (XpsCtx*)ctx;
   if (!connected(c)) return -2;
   if (dst == nullptr && dst32 == nullptr) return -1;
-  const unsigned bpo = blocks_per_owner(c->piece, c->nown);
+  const long long total = (long long)c->piece * c->nown;
+  if (hi <= 0 || hi > total) hi = total;
+  if (lo < 0 || lo >= hi || (lo & 3) || (hi & 3)) return -1;
+  // (sized for the range: a chunk of an eighth of the group does not need the whole group's grid)
+  size_t span = (size_t)(hi - lo) < c->piece ? (size_t)(hi - lo) : c->piece;
+  unsigned bpo = blocks_per_owner(span, c->nown);
   if (dst_is_bf16)
     hipLaunchKernelGGL(xps_pull_kernel<true>, dim3(bpo * c->nown), dim3(256), 0, st, c->ptrs, c->priv, c->nown, c->piece,
-                       c->off_params, dst, dst32, bpo, c->report);
+                       c->off_params, dst, dst32, bpo, c->report, (size_t)lo, (size_t)hi);
   else
     hipLaunchKernelGGL(xps_pull_kernel<false>, dim3(bpo * c->nown), dim3(256), 0, st, c->ptrs, c->priv, c->nown, c->piece,
-                       c->off_params, dst, dst32, bpo, c->report);
+                       c->off_params, dst, dst32, bpo, c->report, (size_t)lo, (size_t)hi);
   return (int)hipGetLastError();
+}
+
+extern "C" int dtfa_xps_pull(void* ctx, void* dst, int dst_is_bf16, float* dst32, hipStream_t st) {
+  return dtfa_xps_pull_range(ctx, dst, dst_is_bf16, dst32, 0, 0, st);
 }
 
 // grad: nown * piece gradient values in the context's gradient dtype.

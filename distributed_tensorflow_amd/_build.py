@@ -29,7 +29,8 @@ OBJDIR = os.path.join(ROOT, "build", "obj")
 
 HIP_ARCH = "gfx950"
 HIP_FLAGS = ["-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-Wno-unused-result"]
-HOST_FLAGS = ["-O3", "-fPIC", "-std=c++17", "-msse4.2", "-pthread", "-Wall", "-Wno-unused-function"]
+HOST_FLAGS = ["-O3", "-fPIC", "-std=c++17", "-msse4.2", "-pthread", "-fno-math-errno", "-ffp-contract=off", "-Wall",
+              "-Wno-unused-function"]
 
 
 def _hipcc() -> str:

@@ -66,6 +66,7 @@ class ConvBnAct(nn.Module):
         """This layer followed by a max-pool, fused on the device (the un-pooled activation is not stored).
         ``weight`` / ``conv_stride`` / ``conv_padding`` run the layer as an equivalent convolution over a
         re-interpreted input (a differentiable function of ``self.weight``, see ``models.resnet``)."""
+        F.param_fence(self)
         if self.training:
             self._coeff_cache = None  # the kernels update the running statistics in place, behind torch's versions
         return F.conv_bn_act_pool(x, self.weight if weight is None else weight, self.gamma, self.beta,
@@ -89,6 +90,7 @@ class ConvBnAct(nn.Module):
         return cached[1]
 
     def forward(self, x, residual=None, links=None, out=None):
+        F.param_fence(self)
         coeffs = None
         if self.training:
             self._coeff_cache = None  # the kernels update the running statistics in place, behind torch's versions
@@ -119,6 +121,7 @@ class Conv2d(nn.Module):
             self.register_parameter("bias", None)
 
     def forward(self, x):
+        F.param_fence(self)
         return F.conv2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding, relu=self.relu)
 
 
@@ -141,6 +144,7 @@ class Dense(nn.Module):
         self.bias._keep_fp32 = True
 
     def forward(self, x):
+        F.param_fence(self)
         return F.dense(x, self.weight, self.bias, relu=self.relu)
 
 

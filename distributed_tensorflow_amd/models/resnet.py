@@ -113,6 +113,7 @@ class ResNet50(nn.Module):
             B, H, W, _ = x.shape
             if not x.is_cuda or W % 2:
                 raise ValueError("4-channel images are the pixel-pair layout of the device stem (even width)")
+            F.param_fence(self.stem)   # (the weight is read here, ahead of the layer's own fence)
             w7 = self.stem.weight
             wp = (w7.reshape(w7.shape[0], 7, 7 * IMAGE_CHANNELS)[:, :, self._pair_idx] * self._pair_mask.to(w7.dtype))
             return self.stem.forward_pool(x.view(B, H, W // 2, 8), (3, 3), (2, 2), (1, 1, 1, 1),

@@ -197,6 +197,36 @@ def _scatter_strided(d, stride, shape):
     return full
 
 
+# ----------------------------------------------------------------------------
+# parameter fence
+# ----------------------------------------------------------------------------
+# An engine that refreshes parameters asynchronously (the all-gather of the sharded mode, the chunked pull of the
+# GPU-resident parameter server) lets the refresh of the last layers' parameters run while the first layers already
+# compute.  Every place that reads a layer's parameters calls ``param_fence(module)`` first; the engine's callback
+# makes the current stream wait for exactly the refreshes that cover this module's parameters.  Without such an
+# engine the call is one global lookup.
+_param_fence_cb = None
+
+
+def set_param_fence(cb) -> None:
+    """``cb(modules)``, a bound method of the engine, or None.  One engine at a time owns the fence (the one created
+    last); it is held weakly, so a discarded engine takes its fence with it."""
+    global _param_fence_cb
+    import weakref
+
+    _param_fence_cb = None if cb is None else weakref.WeakMethod(cb)
+
+
+def param_fence(*modules) -> None:
+    global _param_fence_cb
+    if _param_fence_cb is not None:
+        cb = _param_fence_cb()
+        if cb is None:
+            _param_fence_cb = None
+        else:
+            cb(modules)
+
+
 class Links:
     """The slots of one conv + batch-norm layer (all optional)."""
 
@@ -851,6 +881,7 @@ def expand_dual(x, main, x_in, shortcut, links=None):
     ``x_in`` through the shortcut (for the data-gradient epilogue of the other consumer of ``x_in``)."""
     links = links if links is not None else _NO_LINKS
     plan = cv.get_plan(x.shape[1], x.shape[2], x.shape[3], main.weight.shape[0], 1, 1, 1, 1, (0, 0, 0, 0), x.device)
+    param_fence(main, shortcut)
     return _ExpandDualFn.apply(x, main.weight, main.gamma, main.beta, x_in, shortcut.weight, shortcut.gamma,
                                shortcut.beta, plan, tuple(shortcut.stride), (main.running_mean, main.running_var),
                                (shortcut.running_mean, shortcut.running_var), main.eps, main.momentum,

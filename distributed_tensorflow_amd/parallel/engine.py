@@ -60,7 +60,8 @@ MODES = ("sync_dp", "sharded_ps", "async_ssp")
 class DataParallelEngine:
     def __init__(self, model: nn.Module, *, mode: str = "sync_dp", optimizer: str = "momentum", lr=0.1,
                  opt_kwargs: Optional[dict] = None, bucket_mb: float = 32.0, staleness: int = 1,
-                 process_group=None, grad_dtype: torch.dtype = torch.float32, p2p_max_bytes: int = 0):
+                 process_group=None, grad_dtype: torch.dtype = torch.float32, p2p_max_bytes: int = 0,
+                 overlap_gather: bool = True):
         if mode not in MODES:
             raise ValueError("mode must be one of %s" % (MODES,))
         self.model = model
@@ -90,6 +91,13 @@ class DataParallelEngine:
         self.measure_comm = False
         self._comm_events: List = []
         self._comm_calls = 0
+        # sharded mode: the all-gathers of the updated parameters stay in flight after ``finish_step``; the next
+        # forward waits for a bucket right before the first layer that reads it (ops.functional.param_fence), so the
+        # gather of the last layers' parameters runs while the first layers compute
+        self.overlap_gather = bool(overlap_gather) and mode == "sharded_ps"
+        self._pending_gather: Dict[int, object] = {}
+        self._gather_events: List = []
+        self._gather_steps = 0
         opt_kwargs = dict(opt_kwargs or {})
         if mode == "sharded_ps":
             self._build_shards()
@@ -117,6 +125,15 @@ class DataParallelEngine:
             from .p2p import P2PAllReduce
 
             self._p2p = P2PAllReduce(p2p_max_bytes, group=self.pg)
+        if self.overlap_gather:
+            from ..ops import functional as F
+
+            for m in model.modules():
+                own = [self.flat._bucket_of[id(p)] for p in m._parameters.values()
+                       if p is not None and id(p) in self.flat._bucket_of]
+                if own:
+                    m._dtfa_buckets = list({id(b): b for b in own}.values())
+            F.set_param_fence(self._param_fence)
         if self.collective:
             self.broadcast_parameters()
 
@@ -124,6 +141,7 @@ class DataParallelEngine:
     def broadcast_parameters(self, src: int = 0) -> None:
         """Make every replica start from rank ``src``'s parameters and buffers
         (the reference initialises variables once, on the ps)."""
+        self._wait_all_gathers()
         for g in self.flat.groups:
             dist.broadcast(g.master, src, group=self.pg)
             g.sync_compute_from_master()
@@ -241,6 +259,10 @@ class DataParallelEngine:
         device synchronisation."""
         buckets = [b for g in self.flat.groups for b in g.buckets]
         esz = self.flat.groups[0].grad.element_size() if self.flat.groups else 4
+        if self.mode == "sharded_ps":
+            self._wait_all_gathers()   # (the last step's gathers have no next forward to be waited in)
+            if self.flat.device.type == "cuda":
+                torch.cuda.synchronize(self.flat.device)
         out = {"collective": bool(self.collective), "world": self.world, "mode": self.mode,
                "grad_dtype": str(self.flat.groups[0].grad.dtype).replace("torch.", "") if self.flat.groups else None,
                "buckets": len(buckets), "bucket_bytes": [int(b.numel * esz) for b in buckets],
@@ -250,10 +272,18 @@ class DataParallelEngine:
             ms = [a.elapsed_time(b) for a, b in self._comm_events]
             out["exposed_wait_ms_per_step"] = round(sum(ms) / len(ms), 4)
             out["exposed_wait_ms_max"] = round(max(ms), 4)
+        if self.mode == "sharded_ps":
+            out["overlap_gather"] = self.overlap_gather
+            if self._gather_events and self._gather_steps:
+                # time the compute stream stood still for parameter all-gathers (inside the next forward when they
+                # overlap it, at the end of the step otherwise), per step
+                out["exposed_gather_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in self._gather_events)
+                                                          / self._gather_steps, 4)
         return out
 
     def reset_comm_stats(self) -> None:
         self._comm_events, self._comm_calls = [], 0
+        self._gather_events, self._gather_steps = [], 0
 
     def _opt_step(self, scale: float, prepared: bool) -> None:
         if not prepared:
@@ -268,6 +298,7 @@ class DataParallelEngine:
         caller has run :meth:`prepare_step` and will run :meth:`advance_step` (graph capture)."""
         if prepared and not self.graph_capturable:
             raise ValueError("async_ssp with staleness > 0 rotates buffers per step and cannot be captured")
+        self._wait_all_gathers()   # (parameters no layer asked for: the optimizer is about to rewrite their source)
         self.flat.collect_autograd_grads()
         self._join_side_streams()
         scale = 1.0 / self.world
@@ -277,7 +308,9 @@ class DataParallelEngine:
                     self._grad_shard[g.name].copy_(g.grad)
             self._wait_handles(self._handles)
             self._opt_step(scale, prepared)
-            self._gather_params()
+            # (a captured step must end with its own gathers complete: the replay has no "next forward" to wait in)
+            self._gather_params(defer=self.overlap_gather and not prepared)
+            self._gather_steps += 1
         elif self.mode == "async_ssp" and self.staleness > 0:
             s = self.staleness
             slot = self._step % (s + 1)
@@ -320,23 +353,64 @@ class DataParallelEngine:
             self.optimizer.step(grad_scale=1.0 / self.world)
         self._applied_through = self._step
 
-    def _gather_params(self) -> None:
-        handles = []
+    def _gather_params(self, defer: bool = False) -> None:
+        """All-gather the updated parameter shards, bucket by bucket.  Buckets are laid out last layer first, and a
+        forward pass needs them first layer first: the collectives are issued in reverse bucket order, and with
+        ``defer`` their handles are kept for :meth:`_param_fence` instead of being waited for here."""
+        jobs = []
         for g in self.flat.groups:
             src_all = self._w16_shard[g.name] if self._w16_shard[g.name] is not None else self._master_shard[g.name]
-            dst_all = g.compute
             for b, off, p in self._pieces(g):
-                src = src_all[off:off + p]
-                dst = dst_all[b.start:b.end]
-                if self.collective:
-                    handles.append(dist.all_gather_into_tensor(dst, src, group=self.pg, async_op=True))
+                jobs.append((b, src_all[off:off + p], g.compute[b.start:b.end]))
+        jobs.sort(key=lambda j: -j[0].start)   # within a group: the bucket of the first layers first
+        handles = []
+        for b, src, dst in jobs:
+            if self.collective:
+                h = dist.all_gather_into_tensor(dst, src, group=self.pg, async_op=True)
+                if defer:
+                    self._pending_gather[id(b)] = h
                 else:
-                    dst.copy_(src)
-        self._wait_handles(handles)
+                    handles.append(h)
+            else:
+                dst.copy_(src)
+        if handles:
+            self._timed_gather_wait(handles)
+
+    def _timed_gather_wait(self, handles) -> None:
+        timed = self.measure_comm and self.flat.device.type == "cuda"
+        if timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        for h in handles:
+            h.wait()
+        if timed:
+            b.record()
+            self._gather_events.append((a, b))
+        self._comm_calls += len(handles)
+
+    def _param_fence(self, modules) -> None:
+        """Called right before ``modules``' parameters are read: wait for the gathers that cover them."""
+        if not self._pending_gather:
+            return
+        hs = []
+        for m in modules:
+            for b in getattr(m, "_dtfa_buckets", ()):
+                h = self._pending_gather.pop(id(b), None)
+                if h is not None:
+                    hs.append(h)
+        if hs:
+            self._timed_gather_wait(hs)
+
+    def _wait_all_gathers(self) -> None:
+        if self._pending_gather:
+            hs = list(self._pending_gather.values())
+            self._pending_gather.clear()
+            self._timed_gather_wait(hs)
 
     # ------------------------------------------------------------------ export
     def full_master(self) -> Dict[str, torch.Tensor]:
         """fp32 master parameters of every flat group (gathers shards)."""
+        self._wait_all_gathers()
         out = {}
         for g in self.flat.groups:
             if self.mode != "sharded_ps":
@@ -390,6 +464,7 @@ class DataParallelEngine:
 
     def load_master(self) -> None:
         """Re-derive compute copies (and shards) after ``FlatGroup.master`` was overwritten (restore)."""
+        self._wait_all_gathers()
         for g in self.flat.groups:
             g.sync_compute_from_master()
         if self.mode == "sharded_ps":

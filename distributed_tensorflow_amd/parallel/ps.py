@@ -31,8 +31,10 @@ UTF-8 JSON).
 """
 from __future__ import annotations
 
+import ctypes as C
 import json
 import os
+import queue
 import socket
 import struct
 import threading
@@ -42,7 +44,6 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from ..optim import OptRegion, make_optimizer
 
 MAGIC = b"DTPS"
 HEADER = struct.Struct("<4sIiiqQ")
@@ -99,34 +100,78 @@ def _big_buffers(sock) -> None:
 # ----------------------------------------------------------------------------
 # server
 # ----------------------------------------------------------------------------
+class _NativeOptimizer:
+    """What the rest of the runtime asks of a ps task's optimizer (slot tensors, step count, Adam's powers); the
+    update itself runs in ``csrc/host/ps_core.cc``."""
+
+    def __init__(self, server, name: str, region: str, n: int, opt_kwargs: dict):
+        self._server = server
+        self.name = name.lower()
+        kw = dict(opt_kwargs or {})
+        if self.name == "adam":
+            self.kind = 0
+            self.b1, self.b2, self.eps = float(kw.get("beta1", 0.9)), float(kw.get("beta2", 0.999)), float(kw.get("eps", 1e-8))
+            self.mu, self.nesterov = 0.0, False
+            self._slots = {"Adam/" + region: torch.zeros(n), "Adam_1/" + region: torch.zeros(n)}
+        elif self.name in ("momentum", "sgd"):
+            self.kind = 1
+            self.b1 = self.b2 = self.eps = 0.0
+            self.mu, self.nesterov = float(kw.get("momentum", 0.9)), bool(kw.get("nesterov", False))
+            self._slots = {"Momentum/" + region: torch.zeros(n)}
+        else:
+            raise ValueError("unknown optimizer %r" % name)
+
+    def slots(self) -> Dict[str, torch.Tensor]:
+        return self._slots
+
+    @property
+    def step_count(self) -> int:
+        return self._server.global_step
+
+    @step_count.setter
+    def step_count(self, v: int) -> None:
+        self._server._set_step(int(v))
+
+    @property
+    def beta1_power(self):
+        return self.b1 ** (self.step_count + 1) if self.kind == 0 else None
+
+    @property
+    def beta2_power(self):
+        return self.b2 ** (self.step_count + 1) if self.kind == 0 else None
+
+
 class ParameterServer:
     """One ps task.  ``serve_forever`` blocks like ``server.join()``
     (recognition_flower/distributed/train_dataset.py:142-145) until a SHUTDOWN
-    request arrives."""
+    request arrives.
+
+    This class is the control plane: it accepts connections and answers the rare frames (hello, initialisation,
+    checkpoint state, status, goodbye, shutdown).  The frames of every worker step -- PULL and PUSH -- are served
+    by the native core (``csrc/host/ps_core.cc``), which also owns the clocks, the staleness bound and the global
+    step: a connection thread spends its life inside ``dtfa_ps_serve`` (no GIL) and comes back to Python only for a
+    control frame."""
 
     def __init__(self, host: str, port: int, ps_index: int = 0, staleness: int = -1, worker_timeout: float = 30.0,
-                 debug: Optional[bool] = None):
+                 debug: Optional[bool] = None, apply_threads: int = 4):
         # debug mode (also DTFA_DEBUG_STALENESS=1): the allowed races are asserted on version counters --
         # a pull is never admitted beyond the staleness bound, a worker's clock advances by exactly one per
         # applied push, and the number of applies equals the sum of the clock advances.  Violations are
         # recorded in ``violations`` and answered with an error status instead of being served.
+        from ..io import hostlib
+
         self.debug = bool(int(os.environ.get("DTFA_DEBUG_STALENESS", "0"))) if debug is None else bool(debug)
-        self.violations: List[str] = []
-        self._clock_advances = 0
         self.addr = (host, port)
         self.ps_index = ps_index
         self.staleness = staleness
         self.worker_timeout = worker_timeout
+        self.apply_threads = int(apply_threads)
+        self._L = _core_lib(hostlib.lib())
+        self._core = self._L.dtfa_ps_new(int(staleness), float(worker_timeout), int(self.debug))
         self.lock = threading.Condition()
         self.initialized = False
         self.params: Optional[torch.Tensor] = None
-        self.grad: Optional[torch.Tensor] = None
-        self.optimizer = None
-        self.global_step = 0
-        self.apply_count = 0
-        self.clocks: Dict[int, int] = {}
-        self.last_seen: Dict[int, float] = {}
-        self.max_lag_seen = 0  # largest (clock - min live clock) ever admitted to pull; checked by tests
+        self.optimizer: Optional[_NativeOptimizer] = None
         self._stop = threading.Event()
         self._sock = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         self._sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -136,27 +181,42 @@ class ParameterServer:
         self._threads: List[threading.Thread] = []
         self._conns: List[socket.socket] = []
 
-    # -- staleness bookkeeping -------------------------------------------------
-    def _live_min_clock(self, now: float) -> Optional[int]:
-        live = [c for w, c in self.clocks.items() if now - self.last_seen.get(w, 0) <= self.worker_timeout]
-        return min(live) if live else None
+    # -- state kept by the native core -----------------------------------------------
+    def _status(self):
+        out = (C.c_longlong * 8)()
+        clocks = (C.c_longlong * 128)()
+        self._L.dtfa_ps_status(self._core, out, clocks, 64)
+        return out, {int(clocks[2 * i]): int(clocks[2 * i + 1]) for i in range(int(out[4]))}
 
-    def _wait_for_staleness(self, worker: int, clock: int) -> None:
-        if self.staleness < 0:
-            return
-        with self.lock:
-            while not self._stop.is_set():
-                now = time.time()
-                self.last_seen[worker] = now
-                m = self._live_min_clock(now)
-                if m is None or clock - m <= self.staleness:
-                    if m is not None:
-                        self.max_lag_seen = max(self.max_lag_seen, clock - m)
-                    if self.debug and self.max_lag_seen > self.staleness:
-                        self.violations.append("pull of worker %d admitted at lag %d > %d" % (worker, clock - m,
-                                                                                            self.staleness))
-                    return
-                self.lock.wait(timeout=0.05)
+    @property
+    def global_step(self) -> int:
+        return int(self._status()[0][0])
+
+    @property
+    def apply_count(self) -> int:
+        return int(self._status()[0][1])
+
+    @property
+    def max_lag_seen(self) -> int:
+        """Largest (clock - min live clock) ever admitted to pull; checked by tests."""
+        return int(self._status()[0][2])
+
+    @property
+    def clocks(self) -> Dict[int, int]:
+        return self._status()[1]
+
+    @property
+    def violations(self) -> List[str]:
+        n = int(self._status()[0][3])
+        out = []
+        buf = C.create_string_buffer(512)
+        for i in range(n):
+            if self._L.dtfa_ps_violation(self._core, i, buf, 512) > 0:
+                out.append(buf.value.decode())
+        return out
+
+    def _set_step(self, step: int) -> None:
+        self._L.dtfa_ps_set_step(self._core, int(step))
 
     def _load_slots(self, names, blob, n: int) -> None:
         """Optimizer slots from a state message: ``names[i]`` (a slot kind such as ``Adam`` / ``Adam_1`` /
@@ -170,49 +230,51 @@ class ParameterServer:
             if dst is not None and blob.size >= (i + 2) * n:
                 dst.copy_(torch.from_numpy(blob[(i + 1) * n:(i + 2) * n].copy()))
 
+    def _initialise(self, meta: dict, blob: np.ndarray) -> None:
+        nslots = len(meta.get("slots", []))
+        n_par = blob.size // (1 + nslots)
+        self.params = torch.from_numpy(blob[:n_par].copy())
+        opt = _NativeOptimizer(self, meta.get("optimizer", "adam"), "ps%d" % self.ps_index, n_par, meta.get("opt_kwargs", {}))
+        self.optimizer = opt
+        if nslots:  # a resumed run: the chief hands over the restored optimizer state too
+            self._load_slots(meta["slots"], blob, n_par)
+        decay = meta.get("lr_decay")   # [decay_steps, decay_rate]: the schedule runs on the ps, on its own step count
+        sl = list(opt.slots().values())
+        self._L.dtfa_ps_set_data(self._core, self.params.data_ptr(), sl[0].data_ptr(), sl[1].data_ptr() if len(sl) > 1 else None,
+                                 n_par, opt.kind, float(meta.get("lr", 1e-3)), int(decay[0]) if decay else 0,
+                                 float(decay[1]) if decay else 1.0, opt.b1, opt.b2, opt.eps, opt.mu, 0.0, int(opt.nesterov),
+                                 int(meta.get("global_step", 0)), self.apply_threads)
+        self.initialized = True
+
     # -- request handling --------------------------------------------------------
     def _handle(self, conn: socket.socket) -> None:
         worker = -1
+        hdr = C.create_string_buffer(HEADER.size)
         try:
             conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             _big_buffers(conn)
             while True:
-                op, worker, _, clock, payload = _recv_msg(conn)
-                now = time.time()
-                if self._stop.is_set() and op in (OP_PULL, OP_PUSH, OP_WAIT_INIT, OP_INIT):
+                # PULL / PUSH frames are served natively; this returns with the header of the first other frame
+                rc = self._L.dtfa_ps_serve(self._core, conn.fileno(), hdr)
+                if rc != 1:
+                    return
+                magic, op, worker, _, clock, n = HEADER.unpack(hdr.raw)
+                payload = _recv_exact(conn, n) if n else bytearray()
+                gs = self.global_step
+                if self._stop.is_set() and op in (OP_WAIT_INIT, OP_INIT):
                     # shutting down: tell the worker instead of dropping the connection
-                    _send_msg(conn, op, worker, ST_STOPPED, self.global_step)
+                    _send_msg(conn, op, worker, ST_STOPPED, gs)
                     continue
                 if op == OP_HELLO:
-                    with self.lock:
-                        self.last_seen[worker] = now
-                        self.clocks.setdefault(worker, int(clock))
-                    _send_msg(conn, op, worker, ST_OK if self.initialized else ST_NOT_INIT, self.global_step)
+                    self._L.dtfa_ps_hello(self._core, int(worker), int(clock))
+                    _send_msg(conn, op, worker, ST_OK if self.initialized else ST_NOT_INIT, gs)
                 elif op == OP_INIT:
                     meta_len = struct.unpack("<I", bytes(payload[:4]))[0]
                     meta = json.loads(bytes(payload[4:4 + meta_len]).decode())
-                    blob = np.frombuffer(payload, dtype=np.float32, offset=4 + meta_len).copy()
-                    nslots = len(meta.get("slots", []))
-                    n_par = blob.size // (1 + nslots)
+                    blob = np.frombuffer(payload, dtype=np.float32, offset=4 + meta_len)
                     with self.lock:
                         if not self.initialized:  # first initialiser wins; later ones are ignored
-                            self.params = torch.from_numpy(blob[:n_par])
-                            self.grad = torch.zeros_like(self.params)
-                            lr = float(meta.get("lr", 1e-3))
-                            decay = meta.get("lr_decay")   # [decay_steps, decay_rate]: the schedule runs on the ps,
-                            if decay:                      # on its own count of applied steps
-                                from ..optim.schedules import exponential_decay
-
-                                lr = exponential_decay(lr, int(decay[0]), float(decay[1]))
-                            self.optimizer = make_optimizer(meta.get("optimizer", "adam"),
-                                                            [OptRegion("ps%d" % self.ps_index, self.params, self.grad,
-                                                                       None, False)],
-                                                            lr, **meta.get("opt_kwargs", {}))
-                            self.global_step = int(meta.get("global_step", 0))
-                            self.optimizer.step_count = self.global_step
-                            if nslots:  # a resumed run: the chief hands over the restored optimizer state too
-                                self._load_slots(meta["slots"], blob, n_par)
-                            self.initialized = True
+                            self._initialise(meta, blob)
                             self.lock.notify_all()
                     _send_msg(conn, op, worker, ST_OK, self.global_step)
                 elif op == OP_WAIT_INIT:
@@ -220,90 +282,53 @@ class ParameterServer:
                         while not self.initialized and not self._stop.is_set():
                             self.lock.wait(timeout=0.1)
                     _send_msg(conn, op, worker, ST_OK if self.initialized else ST_STOPPED, self.global_step)
-                elif op == OP_PULL:
-                    if not self.initialized:
-                        _send_msg(conn, op, worker, ST_NOT_INIT, 0)
-                        continue
-                    self._wait_for_staleness(worker, int(clock))
-                    with self.lock:
-                        self.last_seen[worker] = time.time()
-                        data = self.params.numpy().tobytes()
-                        step = self.global_step
-                    _send_msg(conn, op, worker, ST_OK, step, data)
-                elif op == OP_PUSH:
-                    if not self.initialized:
-                        _send_msg(conn, op, worker, ST_NOT_INIT, 0)
-                        continue
-                    g = torch.from_numpy(np.frombuffer(payload, dtype=np.float32))  # the receive buffer itself
-                    with self.lock:
-                        if g.numel() != self.params.numel():
-                            _send_msg(conn, op, worker, ST_ERROR, 0)
-                            continue
-                        if self.debug:
-                            have = self.clocks.get(worker)
-                            if have is not None and int(clock) != have:
-                                self.violations.append("worker %d pushed clock %d, ps holds %d" % (worker, int(clock), have))
-                                _send_msg(conn, op, worker, ST_ERROR, 0)
-                                continue
-                            self._clock_advances += 1
-                            if self._clock_advances != self.apply_count + 1:
-                                self.violations.append("applies %d != clock advances %d" % (self.apply_count + 1,
-                                                                                         self._clock_advances))
-                        self.grad.copy_(g)
-                        self.optimizer.step()
-                        self.apply_count += 1
-                        self.global_step += 1
-                        self.clocks[worker] = int(clock) + 1
-                        self.last_seen[worker] = time.time()
-                        step = self.global_step
-                        self.lock.notify_all()
-                    _send_msg(conn, op, worker, ST_OK, step)
                 elif op == OP_GET_STATE:
-                    with self.lock:
-                        if not self.initialized:
-                            _send_msg(conn, op, worker, ST_NOT_INIT, 0)
-                            continue
+                    if not self.initialized:
+                        _send_msg(conn, op, worker, ST_NOT_INIT, 0)
+                        continue
+                    self._L.dtfa_ps_lock(self._core)   # no apply runs while the variables and slots are copied
+                    try:
                         slots = self.optimizer.slots()
                         names = sorted(slots)
-                        meta = json.dumps({"slots": names, "global_step": self.global_step,
-                                           "apply_count": self.apply_count,
-                                           "beta1_power": getattr(self.optimizer, "beta1_power", None),
-                                           "beta2_power": getattr(self.optimizer, "beta2_power", None)}).encode()
+                        st, _ = self._status()
+                        meta = json.dumps({"slots": names, "global_step": int(st[0]), "apply_count": int(st[1]),
+                                           "beta1_power": self.optimizer.beta1_power,
+                                           "beta2_power": self.optimizer.beta2_power}).encode()
                         blob = b"".join([self.params.numpy().tobytes()] + [slots[k].numpy().tobytes() for k in names])
-                    _send_msg(conn, op, worker, ST_OK, self.global_step, struct.pack("<I", len(meta)) + meta + blob)
+                    finally:
+                        self._L.dtfa_ps_unlock(self._core)
+                    _send_msg(conn, op, worker, ST_OK, int(st[0]), struct.pack("<I", len(meta)) + meta + blob)
                 elif op == OP_SET_STATE:
                     meta_len = struct.unpack("<I", bytes(payload[:4]))[0]
                     meta = json.loads(bytes(payload[4:4 + meta_len]).decode())
                     blob = np.frombuffer(payload, dtype=np.float32, offset=4 + meta_len)
-                    with self.lock:
-                        if not self.initialized:
-                            _send_msg(conn, op, worker, ST_NOT_INIT, 0)
-                            continue
+                    if not self.initialized:
+                        _send_msg(conn, op, worker, ST_NOT_INIT, 0)
+                        continue
+                    self._L.dtfa_ps_lock(self._core)
+                    try:
                         n = self.params.numel()
                         self.params.copy_(torch.from_numpy(blob[:n].copy()))
                         self._load_slots(meta.get("slots", []), blob, n)
-                        self.global_step = int(meta.get("global_step", self.global_step))
-                        self.optimizer.step_count = self.global_step
+                        if "global_step" in meta:
+                            self._set_step(int(meta["global_step"]))
+                    finally:
+                        self._L.dtfa_ps_unlock(self._core)
                     _send_msg(conn, op, worker, ST_OK, self.global_step)
                 elif op == OP_STATUS:
-                    with self.lock:
-                        meta = json.dumps({"initialized": self.initialized, "global_step": self.global_step,
-                                           "clocks": {str(k): v for k, v in self.clocks.items()},
-                                           "max_lag_seen": self.max_lag_seen, "staleness": self.staleness,
-                                           "debug": self.debug, "violations": list(self.violations)}).encode()
-                    _send_msg(conn, op, worker, ST_OK, self.global_step, meta)
+                    st, clocks = self._status()
+                    meta = json.dumps({"initialized": self.initialized, "global_step": int(st[0]),
+                                       "clocks": {str(k): v for k, v in clocks.items()},
+                                       "max_lag_seen": int(st[2]), "staleness": self.staleness,
+                                       "debug": self.debug, "violations": self.violations}).encode()
+                    _send_msg(conn, op, worker, ST_OK, int(st[0]), meta)
                 elif op == OP_BYE:
-                    with self.lock:
-                        self.clocks.pop(worker, None)
-                        self.last_seen.pop(worker, None)
-                        self.lock.notify_all()
-                    _send_msg(conn, op, worker, ST_OK, self.global_step)
+                    self._L.dtfa_ps_bye(self._core, int(worker))
+                    _send_msg(conn, op, worker, ST_OK, gs)
                     return
                 elif op == OP_SHUTDOWN:
-                    _send_msg(conn, op, worker, ST_OK, self.global_step)
-                    self._stop.set()
-                    with self.lock:
-                        self.lock.notify_all()
+                    _send_msg(conn, op, worker, ST_OK, gs)
+                    self.stop()
                     return
                 else:
                     _send_msg(conn, op, worker, ST_ERROR, 0)
@@ -311,11 +336,8 @@ class ParameterServer:
             pass
         finally:
             # a vanished worker must not hold the others back
-            with self.lock:
-                if worker in self.clocks:
-                    self.clocks.pop(worker, None)
-                    self.last_seen.pop(worker, None)
-                self.lock.notify_all()
+            if worker >= 0:
+                self._L.dtfa_ps_bye(self._core, int(worker))
             try:
                 conn.close()
             except OSError:
@@ -355,8 +377,36 @@ class ParameterServer:
 
     def stop(self) -> None:
         self._stop.set()
+        self._L.dtfa_ps_stop(self._core)
         with self.lock:
             self.lock.notify_all()
+
+
+_core_sigs_done = False
+
+
+def _core_lib(L):
+    """ctypes signatures of the native ps core (csrc/host/ps_core.cc)."""
+    global _core_sigs_done
+    if not _core_sigs_done:
+        L.dtfa_ps_new.argtypes = [C.c_int, C.c_double, C.c_int]
+        L.dtfa_ps_new.restype = C.c_void_p
+        L.dtfa_ps_set_data.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_double,
+                                       C.c_longlong, C.c_double, C.c_double, C.c_double, C.c_float, C.c_float, C.c_float,
+                                       C.c_int, C.c_longlong, C.c_int]
+        L.dtfa_ps_set_data.restype = None
+        for name, args in (("dtfa_ps_set_step", [C.c_void_p, C.c_longlong]), ("dtfa_ps_hello", [C.c_void_p, C.c_int, C.c_longlong]),
+                           ("dtfa_ps_bye", [C.c_void_p, C.c_int]), ("dtfa_ps_stop", [C.c_void_p]), ("dtfa_ps_lock", [C.c_void_p]),
+                           ("dtfa_ps_unlock", [C.c_void_p]), ("dtfa_ps_free", [C.c_void_p]),
+                           ("dtfa_ps_status", [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int])):
+            getattr(L, name).argtypes = args
+            getattr(L, name).restype = None
+        L.dtfa_ps_violation.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+        L.dtfa_ps_violation.restype = C.c_int
+        L.dtfa_ps_serve.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+        L.dtfa_ps_serve.restype = C.c_int
+        _core_sigs_done = True
+    return L
 
 
 # ----------------------------------------------------------------------------
@@ -402,12 +452,19 @@ class PSWorkerEngine:
     def __init__(self, model, ps_addresses: List[Tuple[str, int]], worker_index: int, is_chief: bool, *,
                  optimizer: str = "adam", lr: float = 1e-3, opt_kwargs: Optional[dict] = None,
                  connect_timeout: float = 60.0, initial_global_step: int = 0, defer_init: bool = False,
-                 lr_decay: Optional[Tuple[int, float]] = None):
+                 lr_decay: Optional[Tuple[int, float]] = None, pipeline: bool = False):
         """``defer_init`` (chief only): connect, but leave the ps tasks uninitialised until :meth:`initialize`,
         so that a checkpoint can be restored into this engine first and the ps tasks start from the restored
         variables, optimizer slots and global step -- non-chief workers blocked in ``wait_init`` never see the
         un-restored values.  ``lr_decay`` = (decay_steps, decay_rate): exponential decay of ``lr`` over the global
-        step, evaluated on the ps tasks (where the optimizer runs); the chief hands it over at initialisation."""
+        step, evaluated on the ps tasks (where the optimizer runs); the chief hands it over at initialisation.
+
+        ``pipeline``: the network part of a step -- push of this step's gradient, then the pull for a later step --
+        runs on a helper thread while the device computes the next step.  A step then starts from the variables of
+        the newest pull that has COMPLETED, which contain every push up to the step before last at least: one step of
+        staleness on the worker's own gradient, which asynchronous training accepts by definition (the reference
+        reads variables while other workers' ApplyAdam ops are running).  At most one push / pull pair is in flight,
+        so the worker runs at max(device time, network time) per step instead of their sum."""
         from .flat import FlatParams
 
         self.model = model
@@ -438,6 +495,21 @@ class PSWorkerEngine:
         self._stage = [torch.empty(sum(s.numel for _, s in pl), dtype=torch.float32, pin_memory=pin)
                        for pl in self.placement]
         self._stage_np = [t.numpy() for t in self._stage]
+        self.pipeline = bool(pipeline)
+        if self.pipeline:
+            # pulls land in two alternating buffers per ps task (one may still be uploading while the next arrives);
+            # ``_stage`` keeps carrying the gradients
+            self._pstage = [[torch.empty_like(t, pin_memory=pin) for t in self._stage] for _ in range(2)]
+            self._pstage_np = [[t.numpy() for t in row] for row in self._pstage]
+            self._job_done = threading.Event()
+            self._job_done.set()
+            self._job_error: Optional[BaseException] = None
+            self._job_seq = 0            # jobs submitted
+            self._pulled_seq = 0         # newest job whose pull has completed
+            self._uploaded_seq = 0       # newest pull uploaded to the device
+            self._jobs: "queue.Queue" = queue.Queue()
+            self._io = threading.Thread(target=self._io_loop, daemon=True)
+            self._io.start()
         self.conns = [_Conn(h, p, worker_index, connect_timeout) for h, p in ps_addresses]
         for c in self.conns:
             c.call(OP_HELLO, 0)
@@ -518,6 +590,7 @@ class PSWorkerEngine:
 
     # -- protocol ---------------------------------------------------------------
     def pull(self) -> None:
+        self._drain_pipeline()
         if self._stage[0].is_pinned():
             # uploads of an earlier pull may still be reading the staging buffers
             torch.cuda.current_stream(self.flat.device).synchronize()
@@ -538,7 +611,13 @@ class PSWorkerEngine:
         if self._prepared:  # the pull was done by prepare_step (step-graph protocol)
             self._prepared = False
             return
-        self.pull()
+        self._refresh()
+
+    def _refresh(self) -> None:
+        if self.pipeline:
+            self._take_newest_pull()
+        else:
+            self.pull()
 
     # Step-graph protocol (train/graph.py): the device part of a worker step -- forward, backward, gradients
     # into the flat buffer -- is captured once and replayed; the network parts stay on the host around it:
@@ -548,18 +627,18 @@ class PSWorkerEngine:
         return self.flat.device.type == "cuda"
 
     def prepare_step(self) -> None:
-        self.pull()
+        self._refresh()
         self._prepared = True
 
     def advance_step(self) -> int:
         self._prepared = False
-        return self._push()
+        return self._submit() if self.pipeline else self._push()
 
     def finish_step(self, prepared: bool = False) -> int:
         self.flat.collect_autograd_grads()
         if prepared:  # inside a graph capture: the push follows the replay (advance_step)
             return self.global_step
-        return self._push()
+        return self._submit() if self.pipeline else self._push()
 
     def _push(self) -> int:
         for i, c in enumerate(self.conns):
@@ -573,14 +652,103 @@ class PSWorkerEngine:
         self.clock += 1
         return self.global_step
 
+    # -- pipelined network part ---------------------------------------------------
+    def _wait_job(self) -> None:
+        self._job_done.wait()
+        if self._job_error is not None:
+            e, self._job_error = self._job_error, None
+            raise e
+
+    def _submit(self) -> int:
+        """Hand this step's gradient to the helper thread: device-to-host copies are enqueued on the current stream,
+        the thread waits for them, pushes, and pulls.  Waits first for the previous pair (one in flight)."""
+        self._wait_job()
+        for i in range(len(self.conns)):
+            stage, pos = self._stage[i], 0
+            for g, s in self.placement[i]:
+                stage[pos:pos + s.numel].copy_(g.grad[s.offset:s.offset + s.numel].detach(), non_blocking=True)
+                pos += s.numel
+        ev = None
+        if self.flat.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat.device))
+        self._job_seq += 1
+        self._job_done.clear()
+        self._jobs.put((self._job_seq, ev))
+        return self.global_step
+
+    def _io_loop(self) -> None:
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            seq, ev = job
+            try:
+                if ev is not None:
+                    ev.synchronize()
+                for i, c in enumerate(self.conns):
+                    st, step, _ = c.call(OP_PUSH, self.clock, self._stage_np[i])
+                    if st == ST_STOPPED:
+                        raise PSStopped("parameter server is shutting down")
+                    if st != ST_OK:
+                        raise ConnectionError("push failed with status %d" % st)
+                    if i == 0:
+                        self.global_step = int(step)
+                self.clock += 1
+                slot = seq & 1
+                for i, c in enumerate(self.conns):
+                    st, step, data = c.call(OP_PULL, self.clock, into=memoryview(self._pstage_np[slot][i]).cast("B"))
+                    if st == ST_STOPPED:
+                        raise PSStopped("parameter server is shutting down")
+                    if st != ST_OK or len(data) != self._pstage[slot][i].numel() * 4:
+                        raise ConnectionError("pull failed with status %d" % st)
+                    if i == 0:
+                        self.global_step = int(step)
+                self._pulled_seq = seq
+            except BaseException as e:  # noqa: BLE001 -- handed to the training thread at its next wait
+                self._job_error = e
+            finally:
+                self._job_done.set()
+
+    def _take_newest_pull(self) -> None:
+        """Upload the newest completed pull (if it is newer than what the device holds).  Before the first job there
+        is nothing in flight and nothing pulled: a plain pull."""
+        if self._job_seq == 0:
+            self.pull()
+            return
+        if self._job_error is not None:
+            self._wait_job()
+        seq = self._pulled_seq
+        if seq <= self._uploaded_seq:
+            if seq < self._job_seq - 1 or self._uploaded_seq == 0:
+                # (not even the pair before last has come back: wait for it rather than run further ahead)
+                self._wait_job()
+                seq = self._pulled_seq
+            if seq <= self._uploaded_seq:
+                return
+        slot = seq & 1
+        for i in range(len(self.conns)):
+            stage, pos = self._pstage[slot][i], 0
+            for g, s in self.placement[i]:
+                g.master[s.offset:s.offset + s.numel].copy_(stage[pos:pos + s.numel], non_blocking=True)
+                pos += s.numel
+        for g in self.flat.groups:
+            g.sync_compute_from_master()
+        self._uploaded_seq = seq
+
+    def _drain_pipeline(self) -> None:
+        if self.pipeline and self._job_seq:
+            self._wait_job()
 
     def status(self) -> dict:
+        self._drain_pipeline()
         _, _, data = self.conns[0].call(OP_STATUS, self.clock)
         return json.loads(bytes(data).decode())
 
     # -- checkpoint support (used by io.saver.Saver) --------------------------------
     def _fetch_state(self):
         """Full-layout fp32 masters and optimizer slots gathered from every ps."""
+        self._drain_pipeline()   # (the connections carry one conversation at a time)
         masters = {g.name: g.master.clone() for g in self.flat.groups}
         slots: Dict[str, torch.Tensor] = {}
         info = {}
@@ -648,6 +816,7 @@ class PSWorkerEngine:
         """Push restored master values (``FlatGroup.master``) and the restored global step to the ps tasks
         (after initialisation; before it the values simply wait for :meth:`initialize`)."""
         if self.initialized:
+            self._drain_pipeline()
             for i, c in enumerate(self.conns):
                 c.call(OP_SET_STATE, self.clock, self._state_payload(i, {}, {}))
         for g in self.flat.groups:
@@ -659,6 +828,7 @@ class PSWorkerEngine:
         if not self.initialized:
             self._pending_slots = {k: v.detach().clone() for k, v in full.items()}
             return
+        self._drain_pipeline()
         for i, c in enumerate(self.conns):
             c.call(OP_SET_STATE, self.clock, self._state_payload(i, full, {}))
 
@@ -671,6 +841,12 @@ class PSWorkerEngine:
         self.global_step = int(v)
 
     def close(self, shutdown_ps: bool = False) -> None:
+        if self.pipeline:
+            try:
+                self._drain_pipeline()
+            except (ConnectionError, OSError):
+                pass
+            self._jobs.put(None)
         for c in self.conns:
             try:
                 c.call(OP_SHUTDOWN if shutdown_ps else OP_BYE, self.clock)

@@ -71,6 +71,7 @@ _SIGS = {
     "dtfa_xps_join": [C.c_void_p, C.c_void_p],
     "dtfa_xps_gate": [C.c_void_p, C.c_int, C.c_void_p],
     "dtfa_xps_pull": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    "dtfa_xps_pull_range": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p],
     "dtfa_xps_push": [C.c_void_p, C.c_void_p, C.c_void_p],
     "dtfa_xps_apply": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p],
@@ -182,7 +183,8 @@ class XgmiPSEngine:
     def __init__(self, model: nn.Module, *, optimizer: str = "adam", lr=1e-3, opt_kwargs: Optional[dict] = None,
                  staleness: int = -1, apply: str = "auto", grad_dtype: torch.dtype = torch.float32,
                  timeout: float = 30.0, process_group=None, cluster: Optional[XpsCluster] = None,
-                 worker_index: Optional[int] = None, defer_init: bool = False):
+                 worker_index: Optional[int] = None, defer_init: bool = False, overlap_pull: bool = True,
+                 pull_chunks: int = 8):
         self.model = model
         self.pg = process_group
         self.cluster = cluster
@@ -230,6 +232,15 @@ class XgmiPSEngine:
         self._initialized = False
         self._store = None
         self.shards: List[_Region] = []
+        # The pull of a step runs in chunks on a side stream, first layers' parameters first (they sit at the END of
+        # the flat buffers); a layer waits for the chunks that cover its parameters right before it reads them
+        # (ops.functional.param_fence), so the forward starts as soon as the first chunk is in, and the rest of the
+        # pull -- peer reads over xGMI -- runs beside it.
+        self.overlap_pull = bool(overlap_pull)
+        self._pull_stream = None
+        self._pull_events: Dict[tuple, object] = {}     # (group index, chunk) -> event of this step's pull, not yet waited for
+        self._chunks: List[List[tuple]] = []            # per group: [(lo, hi)] in forward order
+        self._pull_waits: List = []
         dev = self.flat.device
         with torch.cuda.device(dev):
             for g in self.flat.groups:
@@ -241,6 +252,8 @@ class XgmiPSEngine:
                 self._connect_through_process_group()
             else:
                 self._connect_through_store()
+            if self.overlap_pull:
+                self._plan_chunks(max(1, int(pull_chunks)))
             if not (defer_init and self.is_chief):
                 self.initialize()
 
@@ -306,6 +319,75 @@ class XgmiPSEngine:
             torch.cuda.synchronize(dev)
             self._base_step = int(self.shards[0].report()[0])
 
+    # ------------------------------------------------------------------ overlapped pull
+    def _plan_chunks(self, k: int) -> None:
+        from ..ops import functional as F
+
+        self._pull_stream = torch.cuda.Stream(device=self.flat.device)
+        seg_of = {}
+        for gi, g in enumerate(self.flat.groups):
+            step = max(64, (g.total // k + 63) // 64 * 64)
+            bounds = [(lo, min(lo + step, g.total)) for lo in range(0, g.total, step)]
+            bounds.reverse()   # parameters are laid out last layer first: the forward needs the tail first
+            self._chunks.append(bounds)
+            for sgm in g.segments:
+                seg_of[id(sgm.param)] = (gi, sgm.offset, sgm.offset + sgm.numel)
+        for m in self.model.modules():
+            need = set()
+            for p in m._parameters.values():
+                if p is None or id(p) not in seg_of:
+                    continue
+                gi, a, z = seg_of[id(p)]
+                need.update((gi, ci) for ci, (lo, hi) in enumerate(self._chunks[gi]) if lo < z and a < hi)
+            if need:
+                m._dtfa_pull_chunks = sorted(need)
+        F.set_param_fence(self._param_fence)
+
+    def _param_fence(self, modules) -> None:
+        if not self._pull_events:
+            return
+        cur = torch.cuda.current_stream(self.flat.device)
+        for m in modules:
+            for key in getattr(m, "_dtfa_pull_chunks", ()):
+                ev = self._pull_events.pop(key, None)
+                if ev is not None:
+                    self._wait_pull(cur, ev)
+
+    def _wait_pull(self, cur, ev) -> None:
+        if self.measure_comm:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(cur)
+            cur.wait_event(ev)
+            b.record(cur)
+            self._pull_waits.append((a, b))
+        else:
+            cur.wait_event(ev)
+
+    def _join_pull(self) -> None:
+        """The current stream waits for whatever is left of this step's pull (parameters no layer asked for)."""
+        if self._pull_events:
+            cur = torch.cuda.current_stream(self.flat.device)
+            for ev in self._pull_events.values():
+                self._wait_pull(cur, ev)
+            self._pull_events.clear()
+
+    def _pull_chunked(self) -> None:
+        L = _lib()
+        cur = torch.cuda.current_stream(self.flat.device)
+        side = self._pull_stream
+        side.wait_stream(cur)     # behind the gate, and behind the previous step's last reads of the parameters
+        with torch.cuda.stream(side):
+            st = side.cuda_stream
+            order = sorted(((ci, gi) for gi, ch in enumerate(self._chunks) for ci in range(len(ch))))
+            for ci, gi in order:   # chunk 0 of every group first: the first layers' weights and batch-norm parameters
+                sh, g = self.shards[gi], self.flat.groups[gi]
+                lo, hi = self._chunks[gi][ci]
+                is_bf16 = g.compute.dtype == torch.bfloat16
+                dst32 = g.master if g.compute is g.master else None
+                dst = g.compute if g.compute is not g.master else None
+                hipk.check(L.dtfa_xps_pull_range(sh.ctx, hipk.ptr(dst), int(is_bf16), hipk.ptr(dst32), lo, hi, st), "xps_pull")
+                self._pull_events[(gi, ci)] = side.record_event()
+
     # ------------------------------------------------------------------ helpers
     def _st(self) -> int:
         return torch.cuda.current_stream(self.flat.device).cuda_stream
@@ -348,6 +430,7 @@ class XgmiPSEngine:
 
     # ------------------------------------------------------------------ protocol
     def pull(self, into_master: bool = False) -> None:
+        self._join_pull()
         L = _lib()
         for sh in self.shards:
             g = sh.group
@@ -361,7 +444,11 @@ class XgmiPSEngine:
         L = _lib()
         for sh in self.shards:
             hipk.check(L.dtfa_xps_gate(sh.ctx, self.staleness, self._st()), "xps_gate")
-        self.pull()
+        if self.overlap_pull:
+            self._join_pull()
+            self._pull_chunked()
+        else:
+            self.pull()
 
     def _step_size(self) -> float:
         lr = self.schedule(self.global_step_estimate)
@@ -397,6 +484,7 @@ class XgmiPSEngine:
         from ..ops import functional as F
 
         F.join_wgrad_stream(self.flat.device)
+        self._join_pull()
         if not prepared:
             self.prepare_step()
         L = _lib()
@@ -425,6 +513,8 @@ class XgmiPSEngine:
 
     def reset_comm_stats(self) -> None:
         self._stats_base = self.state()
+        self._stats_steps0 = self._steps
+        self._pull_waits = []
 
     def comm_stats(self) -> dict:
         """Protocol counters since :meth:`reset_comm_stats` (synchronises the stream): what was pushed, what was
@@ -437,7 +527,12 @@ class XgmiPSEngine:
         def since(k):
             return int(st[k]) - int(base.get(k, 0))
 
-        return {"collective": False, "world": self.nwrk, "owners": self.nown, "mode": self.mode, "backend": self.backend,
+        extra = {"overlap_pull": self.overlap_pull}
+        steps = self._steps - getattr(self, "_stats_steps0", 0)
+        if self._pull_waits and steps > 0:
+            # time the compute stream stood still for chunks of the pull that had not arrived when a layer needed them
+            extra["exposed_pull_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in self._pull_waits) / steps, 4)
+        return {**extra, "collective": False, "world": self.nwrk, "owners": self.nown, "mode": self.mode, "backend": self.backend,
                 "owned_by": "ps tasks" if self.cluster is not None else "workers",
                 "apply": self.apply, "staleness": self.staleness,
                 "grad_dtype": str(self.shards[0].group.grad.dtype).replace("torch.", "") if self.shards else None,

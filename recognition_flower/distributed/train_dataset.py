@@ -83,6 +83,8 @@ flags.DEFINE_string("ps_backend", "tcp", "async_ps: tcp (ps processes over TCP, 
                     "the owner's memory and variables pulled from it over xGMI peer access; ps tasks have nothing to do)")
 flags.DEFINE_string("ps_apply", "auto", "ps_backend=xgmi: per_push (one optimizer step per arrived gradient, the reference's ps) | "
                     "aggregate (staleness 0 only: one step per round on the sum of the workers' gradients) | auto")
+flags.DEFINE_string("ps_pipeline", "auto", "ps_backend=tcp: push and pull on a helper thread while the device computes the next step (one "
+                    "more step of staleness on the worker's own gradient) -- true | false | auto (on unless --staleness=0)")
 flags.DEFINE_string("optimizer", "adam", "adam (the reference) | momentum")
 flags.DEFINE_float("momentum", 0.9, "momentum optimizer: heavy-ball coefficient.")
 flags.DEFINE_float("weight_decay", 0.0, "momentum optimizer: L2 weight decay on convolution / dense kernels.")
@@ -269,7 +271,8 @@ def run_worker(spec):
         # a resuming chief restores the checkpoint first and initialises the ps tasks from it
         engine = PSWorkerEngine(model, ps_addr, task_index, is_chief, optimizer=opt_name, lr=lr, opt_kwargs=opt_kwargs,
                                 defer_init=FLAGS.resume and is_chief,
-                                lr_decay=(FLAGS.lr_decay_steps, FLAGS.lr_decay_rate) if FLAGS.lr_decay_steps > 0 else None)
+                                lr_decay=(FLAGS.lr_decay_steps, FLAGS.lr_decay_rate) if FLAGS.lr_decay_steps > 0 else None,
+                                pipeline=_flag_on(FLAGS.ps_pipeline, FLAGS.staleness != 0, "--ps_pipeline"))
     else:
         import torch.distributed as dist
         from distributed_tensorflow_amd.parallel.engine import DataParallelEngine
@@ -347,15 +350,19 @@ def run_worker(spec):
     return 0
 
 
-def _want_hip_graph() -> bool:
-    v = str(FLAGS.hip_graph).strip().lower()
+def _flag_on(value, auto: bool, name: str) -> bool:
+    v = str(value).strip().lower()
     if v in ("auto", ""):
-        return FLAGS.mode == "async_ps"
+        return bool(auto)
     if v in ("1", "true", "yes", "on"):
         return True
     if v in ("0", "false", "no", "off"):
         return False
-    raise ValueError("--hip_graph must be true, false or auto (got %r)" % FLAGS.hip_graph)
+    raise ValueError("%s must be true, false or auto (got %r)" % (name, value))
+
+
+def _want_hip_graph() -> bool:
+    return _flag_on(FLAGS.hip_graph, FLAGS.mode == "async_ps", "--hip_graph")
 
 
 def run_evaluator(spec):

@@ -178,6 +178,13 @@ def main():
             if t == 6:
                 applied_mid = eng.state()["applied_per_shard"]
         torch.cuda.synchronize()
+        # the survivors meet through files (the dead rank cannot take part in a barrier): nobody reads the final
+        # state or leaves before both have finished their steps
+        open(os.path.join(out_dir, "dead_done_r%d" % rank), "w").close()
+        t_end = time.time() + 60
+        while not all(os.path.exists(os.path.join(out_dir, "dead_done_r%d" % r)) for r in range(world - 1)):
+            assert time.time() < t_end
+            time.sleep(0.05)
         time.sleep(0.5)
         eng.drain()
         st = eng.state()
@@ -193,6 +200,10 @@ def main():
             assert st["applied_per_shard"][o] > applied_mid[o] > 2, (o, applied_mid, st)
         assert min(st["applied_per_shard"]) >= 2 * 9, st     # two live workers x the steps after the take-over
         assert losses[-1] < 0.5 * losses[0], losses
+        open(os.path.join(out_dir, "dead_checked_r%d" % rank), "w").close()
+        while not all(os.path.exists(os.path.join(out_dir, "dead_checked_r%d" % r)) for r in range(world - 1)):
+            assert time.time() < t_end + 60
+            time.sleep(0.05)
         eng.close()
     elif mode == "ckpt":
         # checkpoint through the Saver: masters and slots gathered by one-sided reads, restored into a new engine

@@ -57,12 +57,18 @@ def _worker(rank, world, port, mode, opt, steps, staleness, out_dir):
                 for p in model.parameters():
                     p.add_(1.0)
         okw = {"momentum": 0.9, "weight_decay": 1e-3} if opt == "momentum" else {}
-        eng = DataParallelEngine(model, mode=mode, optimizer=opt, lr=0.05 if opt == "momentum" else 1e-2,
-                                 opt_kwargs=okw, bucket_mb=0.02, staleness=staleness)
+        blocking = mode.endswith("_blocking")   # sharded mode with every all-gather waited for inside finish_step
+        eng = DataParallelEngine(model, mode=mode.replace("_blocking", ""), optimizer=opt, lr=0.05 if opt == "momentum" else 1e-2,
+                                 opt_kwargs=okw, bucket_mb=0.02, staleness=staleness, overlap_gather=not blocking)
+        if mode == "sharded_ps":
+            assert eng.overlap_gather and len(eng.flat.buckets()) > 3
         for t in range(steps):
             eng.begin_step()
             _loss(model, *_batch(rank, t)).backward()
             eng.finish_step()
+            if mode == "sharded_ps" and world > 1:
+                # the parameter all-gathers are still in flight: the next forward's layers wait for them one by one
+                assert len(eng._pending_gather) == len(eng.flat.buckets())
         eng.drain()
         eng.full_master()  # (sharded mode: gathers the owners' fp32 shards back into FlatGroup.master)
         # compare parameter by parameter: bucket padding differs between modes, values must not
@@ -106,6 +112,16 @@ def _reference(opt, steps, delay=0, world=2):
                 g.grad.copy_(s)
             e.optimizer.step(grad_scale=1.0 / world)
     return torch.cat([g.master[s.offset:s.offset + s.numel] for g in engs[0].flat.groups for s in g.segments])
+
+
+def test_overlapped_parameter_gather_equals_the_blocking_one(tmp_path):
+    """sharded_ps at world 4: all-gathers left in flight after ``finish_step`` and waited for layer by layer in the
+    next forward (ops.functional.param_fence) give bit for bit the parameters of gathers waited for on the spot."""
+    a = _spawn("sharded_ps", "momentum", 4, 0, str(tmp_path), world=4)
+    b = _spawn("sharded_ps_blocking", "momentum", 4, 0, str(tmp_path), world=4)
+    for r in range(4):
+        assert torch.equal(a[r]["flat"], b[r]["flat"]) and torch.equal(a[r]["compute"], b[r]["compute"])
+        assert torch.equal(a[r]["compute"], a[0]["compute"])
 
 
 @pytest.mark.parametrize("opt", ["momentum", "adam"])

@@ -131,6 +131,36 @@ def test_learning_rate_decay_runs_on_the_ps(servers):
     eng.close()
 
 
+def test_pipelined_worker_overlaps_network_and_compute_without_losing_a_push(servers):
+    """``pipeline=True``: push and pull run on a helper thread; every gradient is applied exactly once, a step never
+    starts from variables older than the push before last, and training still descends."""
+    (ps, addr), (ps2, addr2) = servers(2, debug=True)
+    model = _model(1)
+    eng = PSWorkerEngine(model, [addr, addr2], 0, True, optimizer="adam", lr=1e-2, pipeline=True)
+    losses = []
+    for t in range(12):
+        eng.begin_step()
+        logits, reg = model(_batch(0)[0])          # one fixed batch: the loss must fall
+        loss, _, _, _ = F.softmax_xent(logits, _batch(0)[1], 5)
+        (loss + reg).backward()
+        eng.finish_step()
+        losses.append(float(loss))
+        # at most one push / pull pair in flight: everything but the newest push has been acknowledged
+        assert eng._job_seq == t + 1 and eng._pulled_seq >= t
+        assert eng._uploaded_seq >= t - 1
+    st = eng.status()   # (waits for the pair in flight)
+    assert st["global_step"] == 12 and ps.global_step == 12 and ps2.global_step == 12
+    assert st["violations"] == [] and ps2.violations == []
+    assert losses[-1] < 0.7 * losses[0], losses
+    eng.pull()
+    a = torch.cat([p.detach().flatten() for p in model.parameters()])
+    eng2 = PSWorkerEngine(_model(5), [addr, addr2], 1, False, optimizer="adam", lr=1e-2)
+    b = torch.cat([p.detach().flatten() for p in eng2.model.parameters()])
+    torch.testing.assert_close(a, b, rtol=0, atol=0)
+    eng.close()
+    eng2.close()
+
+
 def test_variables_are_placed_round_robin_over_ps_tasks(servers):
     pair = servers(2)
     addrs = [a for _, a in pair]
