@@ -58,7 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--p2p_kb", type=int, default=0,
                     help="gradient buckets up to this many KiB use the one-shot xGMI mailbox all-reduce (sync_dp)")
     ap.add_argument("--trunk_bn", default="batch", choices=["batch", "moving"],
-                    help="inception_v3_head: trunk batch-norm on batch statistics (reference) or frozen moving statistics")
+                    help="inception_v3_*: trunk batch-norm on batch statistics (reference) or frozen moving statistics")
     ap.add_argument("--also", default="flower_cnn",
                     help="second model measured after the headline one and reported under \"also\" ('' = none)")
     ap.add_argument("--also_batch", type=int, default=0, help="per-GPU batch of the second model (default: its own)")
@@ -179,7 +179,7 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
     mode = mode or args.mode
     size = args.image_size or IMAGE_SIZE[model_name]
     torch.manual_seed(1234)
-    kw = {"trunk_bn": args.trunk_bn} if model_name == "inception_v3_head" else {}
+    kw = {"trunk_bn": args.trunk_bn} if model_name.startswith("inception_v3") else {}
     model = build_model(model_name, num_classes=5, device=device, **kw)
     model.train()
     if model_name.startswith("inception_v3"):

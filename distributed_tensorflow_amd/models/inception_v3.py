@@ -283,8 +283,6 @@ class InceptionV3Flower(nn.Module):
         super().__init__()
         if trunk_bn not in ("batch", "moving"):
             raise ValueError("trunk_bn must be 'batch' or 'moving'")
-        if train_trunk and trunk_bn != "batch":
-            raise ValueError("a trained trunk normalises with batch statistics (trunk_bn='batch')")
         self.trunk_bn = trunk_bn
         self.train_trunk = bool(train_trunk)
         self.num_classes = num_classes

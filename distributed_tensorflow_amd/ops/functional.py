@@ -397,6 +397,10 @@ class _ConvBnActFn(Function):
         else:
             scale, shift = K.bn_eval_coeffs(gamma, beta, run_mean, run_var, eps)
             mean = invstd = None
+            if (gamma is not None and ctx.needs_input_grad[2]) or ctx.needs_input_grad[3]:
+                # fine-tuning on frozen statistics: the backward pass needs them for the scale's gradient
+                mean = run_mean.detach().float().clone()
+                invstd = torch.rsqrt(run_var.detach().float() + eps)
         # ReLU backward needs the sign of the output only.  Without a residual it is recomputed from y;
         # with one it is stored as a bitmask (1/16 of the activation's bytes) written by the same pass.
         want_mask = need_grad and training and relu and residual is not None
@@ -478,8 +482,9 @@ class _ConvBnActFn(Function):
                     dres = g
             dy = (g.float() * scale).to(BF16)
             dgamma = dbeta = None
-            if gamma is not None and ctx.needs_input_grad[2]:
-                raise NotImplementedError("gradients of frozen-statistics batch-norm parameters")
+            if mean is not None:
+                # z = gamma * (y - moving_mean) * moving_invstd + beta: sums of g and of g * xhat over the pixels
+                dgamma, dbeta = K.bn_frozen_param_grads(g.contiguous(), y, mean, invstd)
         gx = gw = gg = gb = None
         if ctx.needs_input_grad[1]:
             gw = _deliver_wgrad(wparam if wparam is not None else weight, x, dy, plan)

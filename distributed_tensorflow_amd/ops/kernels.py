@@ -290,6 +290,24 @@ def bn_backward_coefs(dz, y, mean, invstd, gamma, relu: bool = False, zout=None,
     return coef, dgamma, dbeta
 
 
+def bn_frozen_param_grads(g: torch.Tensor, y: torch.Tensor, mean: torch.Tensor, invstd: torch.Tensor):
+    """Gradients of the scale and offset of a batch-norm that normalises with FIXED statistics (moving averages):
+    ``z = gamma * (y - mean) * invstd + beta`` gives ``dbeta = sum g`` and ``dgamma = sum g * (y - mean) * invstd``
+    over the pixels, with ``g`` the (already gated) gradient of ``z``.  Returns ``(dgamma, dbeta)``, fp32 ``[C]``."""
+    hipk.require(g, BF16, "g")
+    hipk.require(y, BF16, "y")
+    if g.shape != y.shape:
+        raise ValueError("g/y shape mismatch")
+    M, Cc = _as2d(y)
+    L = hipk.lib()
+    rows = L.dtfa_col_partials_rows(M, Cc)
+    part = torch.empty((rows, 2, Cc), dtype=F32, device=y.device)
+    hipk.check(L.dtfa_bn_bwd_partials(g.data_ptr(), y.data_ptr(), None, mean.data_ptr(), invstd.data_ptr(), None, None,
+                                      part.data_ptr(), M, Cc, 0, hipk.stream()), "bn_bwd_partials")
+    tot = sum_partial_rows(part)
+    return tot[1], tot[0]
+
+
 def bn_backward_apply(dz, y, coef, relu: bool = False, zout=None, want_dres: bool = False, scale=None, shift=None,
                       mask=None):
     """Second half: ``dy = coef[0]*g + coef[1]*y + coef[2]`` (and ``dres = g`` on request)."""

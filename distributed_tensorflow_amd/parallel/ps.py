@@ -674,6 +674,9 @@ class PSWorkerEngine:
             ev.record(torch.cuda.current_stream(self.flat.device))
         self._job_seq += 1
         self._job_done.clear()
+        # the push in flight counts: the step budget is compared with what the ps tasks WILL hold when it lands (the
+        # helper thread replaces this with their answer, which other workers' pushes can only make larger)
+        self.global_step += 1
         self._jobs.put((self._job_seq, ev))
         return self.global_step
 

@@ -223,7 +223,7 @@ def run_worker(spec):
     if model_name == "inception_v3_head":
         kw = {"head_dropout_rate": FLAGS.head_dropout_rate, "trunk_bn": FLAGS.trunk_bn}
     elif model_name == "inception_v3_finetune":
-        kw = {"head_dropout_rate": FLAGS.head_dropout_rate}
+        kw = {"head_dropout_rate": FLAGS.head_dropout_rate, "trunk_bn": FLAGS.trunk_bn}
     else:
         kw = {"dropout_rate": FLAGS.head_dropout_rate} if model_name == "flower_cnn" else {}
     model = build_model(model_name, num_classes=n_classes, device=device, **kw)

@@ -406,3 +406,65 @@ def test_statistics_accumulators_with_forked_branches(monkeypatch, captured):
         assert torch.isfinite(a).all()
         assert (a - ref).abs().mean() <= 2e-3 * ref.abs().mean() + 1e-4
         torch.testing.assert_close(a, ref, rtol=5e-2, atol=5e-2)
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_frozen_statistics_layer_trains_its_scale_and_offset(relu):
+    """A conv + batch-norm layer in eval mode (moving statistics) inside a training graph -- fine-tuning with
+    ``trunk_bn="moving"`` -- returns gradients for weight, gamma and beta that match fp32 autograd of
+    ``act(gamma * (conv(x) - moving_mean) / sqrt(moving_var + eps) + beta)``."""
+    from distributed_tensorflow_amd.models.layers import ConvBnAct
+    from distributed_tensorflow_amd.ops import ref
+
+    torch.manual_seed(3)
+    layer = ConvBnAct(16, 32, 3, 1, "SAME", relu=relu)
+    with torch.no_grad():
+        layer.gamma.uniform_(0.5, 1.5)
+        layer.beta.uniform_(-0.3, 0.3)
+        layer.running_mean.uniform_(-0.2, 0.2)
+        layer.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(4, 12, 12, 16)
+    # fp32 reference on the bf16-rounded operands
+    xr = x.bfloat16().float().requires_grad_(True)
+    wr = layer.weight.detach().bfloat16().float().requires_grad_(True)
+    gr = layer.gamma.detach().clone().requires_grad_(True)
+    br = layer.beta.detach().clone().requires_grad_(True)
+    y = ref.conv2d(xr, wr, (1, 1), (1, 1, 1, 1))
+    z = ref.batch_norm_eval(y, gr, br, layer.running_mean, layer.running_var, layer.eps)
+    if relu:
+        z = torch.relu(z)
+    up = torch.randn_like(z)
+    (z * up).sum().backward()
+
+    dev = cast_for_device(copy.deepcopy(layer), "cuda").eval()
+    xd = x.cuda().bfloat16().requires_grad_(True)
+    zd = dev(xd)
+    (zd.float() * up.cuda()).sum().backward()
+    assert (zd.float().cpu() - z).abs().max().item() <= 3e-2 * z.abs().max().item()
+    for name, got, want in (("gamma", dev.gamma.grad, gr.grad), ("beta", dev.beta.grad, br.grad),
+                            ("weight", dev.weight.grad, wr.grad), ("x", xd.grad, xr.grad)):
+        assert got is not None, name
+        err = (got.float().cpu() - want).norm().item()
+        assert err <= 3e-2 * want.norm().item() + 1e-4, (name, err, want.norm().item())
+
+
+def test_inception_finetune_on_moving_statistics_takes_a_step():
+    """``inception_v3_finetune`` with ``trunk_bn="moving"``: the trunk's convolutions and batch-norm offsets train while
+    every batch-norm normalises with its (frozen) moving statistics; one step gives finite, non-zero gradients all
+    the way down to the stem and leaves the moving statistics untouched."""
+    torch.manual_seed(0)
+    model = build_model("inception_v3_finetune", device="cuda", trunk_bn="moving").train()
+    eng = DataParallelEngine(model, mode="sync_dp", optimizer="adam", lr=1e-4)
+    before = model.trunk.Conv2d_1a_3x3.running_var.clone()
+    x, y = _images(2, 299, seed=3)
+    eng.begin_step()
+    logits, reg = model(x.cuda().bfloat16())
+    loss, _, _, _ = F.softmax_xent(logits, y.cuda().to(torch.int32), 5)
+    (loss + reg).backward()
+    stem = model.trunk.Conv2d_1a_3x3
+    gw, gb = stem.weight.main_grad.float(), stem.beta.main_grad.float()
+    eng.finish_step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).item() and torch.isfinite(gw).all() and torch.isfinite(gb).all()
+    assert gw.abs().max().item() > 0 and gb.abs().max().item() > 0
+    assert torch.equal(model.trunk.Conv2d_1a_3x3.running_var, before)
