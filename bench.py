@@ -73,6 +73,8 @@ def parse_args(argv=None):
     ap.add_argument("--hip_graph", type=int, default=-1,
                     help="1: record the whole step (fwd, bwd, collectives, optimizer) in a HIP graph and replay it; "
                          "default: on for inception_v3_head (hundreds of short kernels per step), off otherwise")
+    ap.add_argument("--rccl_channels", type=int, default=0,
+                    help="channels RCCL runs side by side (NCCL_MIN/MAX_NCHANNELS; 0: RCCL's own choice for the topology)")
     ap.add_argument("--launch_timeout", type=int, default=0,
                     help="launcher: seconds after which the rank processes are stopped (0 = no limit)")
     args = ap.parse_args(argv)
@@ -295,6 +297,9 @@ def run_rank(args) -> int:
     import torch
     import torch.distributed as dist
 
+    from distributed_tensorflow_amd.parallel.rccl import configure_rccl
+
+    rccl_vars = configure_rccl(args.rccl_channels)   # (before the process group exists)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -365,6 +370,7 @@ def run_rank(args) -> int:
             # waiting for collectives that backward did not hide
             "rccl_world": dist.get_world_size() if dist.is_initialized() else 0,
             "rank_devices": devices,
+            "rccl_env": rccl_vars,   # every NCCL_* / RCCL_* variable in force (empty: the library's defaults)
             "comm": head["comm"],
             "also": secondary,
         }), flush=True)

@@ -74,6 +74,7 @@ class DataParallelEngine:
         # (a one-rank RCCL run then exercises the same calls as a multi-GPU job)
         self.collective = self.distributed and (self.world > 1 or os.environ.get("DTFA_FORCE_COLLECTIVES") == "1")
         self.staleness = max(0, int(staleness)) if mode == "async_ssp" else 0
+        self.bucket_source = "given"
         shard_multiple = self.world if mode == "sharded_ps" else 1
         if bucket_mb <= 0:
             # automatic: 32 MiB for models with at least two such buckets of gradient; a small model (the flower CNN
@@ -82,6 +83,14 @@ class DataParallelEngine:
             esz = torch.empty((), dtype=grad_dtype).element_size()
             total_mb = sum(p.numel() for p in model.parameters() if p.requires_grad) * esz / float(1 << 20)
             bucket_mb = 32.0 if total_mb >= 64.0 else max(1.0, total_mb / 4.0)
+            # ... unless this machine's table has a measured winner for this world, mode and model size
+            # (tools/tune_buckets.py; parallel/rccl.py)
+            from .rccl import tuned_bucket_mb
+
+            measured = tuned_bucket_mb(self.world, mode, total_mb) if self.world > 1 else None
+            self.bucket_source = "rule" if measured is None else "measured"
+            if measured is not None:
+                bucket_mb = measured
         self.flat = FlatParams(model, bucket_mb=bucket_mb, shard_multiple=shard_multiple, grad_dtype=grad_dtype)
         self.flat.on_bucket_ready = self._on_bucket_ready
         self._handles: List = []
@@ -266,6 +275,7 @@ class DataParallelEngine:
         out = {"collective": bool(self.collective), "world": self.world, "mode": self.mode,
                "grad_dtype": str(self.flat.groups[0].grad.dtype).replace("torch.", "") if self.flat.groups else None,
                "buckets": len(buckets), "bucket_bytes": [int(b.numel * esz) for b in buckets],
+               "bucket_size_from": self.bucket_source,
                "gradient_bytes": int(sum(b.numel for b in buckets) * esz),
                "collectives_waited": self._comm_calls}
         if self._comm_events:

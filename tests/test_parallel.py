@@ -418,3 +418,24 @@ def test_automatic_bucket_size_cuts_small_models_in_several_buckets():
     assert o["buckets"] == 1 and a["buckets"] >= 4
     assert max(a["bucket_bytes"]) <= 2.1 * (1 << 20) + 4 * 512 * 4
     assert a["gradient_bytes"] == o["gradient_bytes"]
+
+
+def test_measured_bucket_table_feeds_the_automatic_bucket_size(tmp_path, monkeypatch):
+    """parallel/rccl.py: a recorded measurement for (world, mode, gradient size) is what ``bucket_mb=0`` resolves to;
+    other worlds / modes / far-away model sizes fall back to the rule; RCCL channel overrides reach the environment."""
+    from distributed_tensorflow_amd.parallel import rccl
+
+    monkeypatch.setattr(rccl, "_TABLE", str(tmp_path / "tuned_buckets.json"))
+    assert rccl.tuned_bucket_mb(8, "sync_dp", 90.0) is None
+    rccl.record_bucket(8, "sync_dp", "resnet50", 89.8, 16.0, [{"bucket_mb": 16.0, "images_per_sec": 1.0}])
+    rccl.record_bucket(8, "sync_dp", "flower_cnn", 8.0, 2.0, [])
+    assert rccl.tuned_bucket_mb(8, "sync_dp", 95.0) == 16.0
+    assert rccl.tuned_bucket_mb(8, "sync_dp", 7.0) == 2.0
+    assert rccl.tuned_bucket_mb(8, "sync_dp", 400.0) is None
+    assert rccl.tuned_bucket_mb(4, "sync_dp", 90.0) is None and rccl.tuned_bucket_mb(8, "sharded_ps", 90.0) is None
+    rccl.record_bucket(8, "sync_dp", "resnet50", 89.8, 64.0, [])     # a new measurement replaces the old one
+    assert rccl.tuned_bucket_mb(8, "sync_dp", 90.0) == 64.0
+    for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS"):
+        monkeypatch.delenv(k, raising=False)
+    env = rccl.configure_rccl(channels=28)
+    assert env["NCCL_MIN_NCHANNELS"] == "28" and env["NCCL_MAX_NCHANNELS"] == "28"
