@@ -505,193 +505,9 @@ static int launch_conv_epi(const ConvArgs& a, hipStream_t stream) {
   return launch_conv<BM, BN, BK, 0, NST, WG, KSP>(a, stream);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Same-size 3x3 (any taps within +-1 pixel), stride 1, 64 input channels: the pixel operand staged ONCE per tile.
-//
-// For these layers (56x56 64->64 of ResNet, 112x112 64->32 data gradients) the ordinary kernel moves every input
-// pixel nine times from L2 into LDS -- 11 GB per launch at batch 2048, at the ~12 TB/s that path delivers -- although
-// the nine taps of a 128-row tile touch only the flattened pixel range [m0 - IW - 1, m0 + 127 + IW + 1].  Here
-// that range (a "patch" of 128 + 2 (IW + 1) pixel rows of 128 bytes) is brought in once; tap (dy, dx) reads its A
-// fragments at the row offset dy * IW + dx, rows whose tap falls outside the image are pointed at a row of zeros,
-// and the weights do not pass through LDS at all: each lane loads its B fragments from global memory one tap ahead
-// (the 73 KB matrix is shared by every tile).  Between the arrival of the patch and the epilogue there is no barrier.
-// Output tile 128 x 64, 2 x 2 waves, accumulators and epilogue as in conv_igemm_kernel<128, 64, ...>.
-// ---------------------------------------------------------------------------------------------------------------
-#ifndef HALO_OCC
-#define HALO_OCC 4
-#endif
-// timing-only builds (wrong results): bit 0 drops the tap loop, bit 1 the epilogue, bit 2 the patch loads
-#ifndef HALO_DBG
-#define HALO_DBG 0
-#endif
-template <int EPI>
-__global__ __launch_bounds__(256, HALO_OCC) void conv_halo_kernel(ConvArgs p, int patch_rows) {
-  constexpr int BM = 128, BN = 64, ROWB = 128, WM = 64, WN = 32, MT = 2, NT = 1;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* lds_taps = (int*)smem;
-  char* zrow = smem + MAX_TAPS * 4;          // 128 bytes of zeros
-  char* patch = zrow + 128;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 1, wc = wid & 1;
-  const unsigned mtiles = (p.M + BM - 1) / BM;
-  const unsigned ntiles = (p.Cout + BN - 1) / BN;
-  const unsigned bid = xcd_remap(blockIdx.x, mtiles * ntiles);
-  const unsigned tile_m = bid / ntiles, tile_n = bid % ntiles;
-  const int m0 = (int)(tile_m * BM), n0 = tile_n * BN;
-  const int margin = p.IW + 1;
-
-  if (tid < p.T) lds_taps[tid] = p.taps[tid];
-  if (tid < 32) ((float*)zrow)[tid] = 0.f;
-
-  // ---- the patch: 8 pixel rows per wave instruction, dealt over the waves ----
-  const int slot = lane & 7, row_in_inst = lane >> 3;
-  const int ninst = patch_rows >> 3;
-  const long long gp0 = (long long)m0 - margin;
-  for (int j = wid; j < ((HALO_DBG & 4) ? 0 : ninst); j += 4) {
-    const int row = j * 8 + row_in_inst;
-    const long long gp = gp0 + row;
-    const int c = slot ^ swz_of_row<64>(row);
-    const bf16* src = (gp >= 0 && gp < (long long)p.M) ? p.x + (size_t)gp * 64 + c * 8 : p.zero;
-    glds16(src, patch + j * 1024);
-  }
-
-  // ---- weights: every lane fetches its own B fragments (row n, its half of each 16-deep k-step) from global
-  // memory, one tap ahead; the 73 KB weight matrix is shared by all tiles and stays in the caches ----
-  const int khalf = lane >> 5;
-  const int n = n0 + wc * WN + (lane & 31);
-  const bool nok = n < p.Cout;
-  const bool wave_live = n0 + wc * WN < p.Cout;
-  const bf16* wrow = p.w + (size_t)(nok ? n : 0) * p.K + khalf * 8;
-  bf16x8 bnext[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) bnext[ks] = *(const bf16x8*)(wrow + ks * 16);
-
-  // ---- per-lane rows: validity of every tap ----
-  const int opix = p.IH * p.IW;
-  int rloc[MT];
-  unsigned okmask[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    rloc[mt] = wr * WM + mt * 32 + (lane & 31);
-    okmask[mt] = 0;
-  }
-  __syncthreads();   // tap table and zero row visible (the DMA loads are still in flight)
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = m0 + rloc[mt];
-    if (m < p.M) {
-      const int rem = m % opix;
-      const int oy = rem / p.IW, ox = rem - oy * p.IW;
-      for (int t = 0; t < p.T; ++t) {
-        const int tp = lds_taps[t];
-        const int iy = oy + (tp >> 16), ix = ox + (int)(short)(tp & 0xffff);
-        if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) okmask[mt] |= 1u << t;
-      }
-    }
-  }
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[mt][0][j] = 0.f;
-
-  wait_vmcnt<0>();
-  __syncthreads();   // the patch is in LDS; from here to the epilogue the waves run without barriers
-
-  if (wave_live) {
-    for (int t = 0; t < ((HALO_DBG & 1) ? 0 : p.T); ++t) {
-      bf16x8 bcur[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) bcur[ks] = nok ? bnext[ks] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (t + 1 < p.T && !(HALO_DBG & 8)) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) bnext[ks] = *(const bf16x8*)(wrow + (t + 1) * 64 + ks * 16);
-      }
-      const int tp = lds_taps[t];
-      const int toff = (tp >> 16) * p.IW + (int)(short)(tp & 0xffff) + margin;
-      const char* arow[MT];
-      int aswz[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int r = rloc[mt] + toff;
-        const bool ok = (okmask[mt] >> t) & 1u;
-        arow[mt] = ok ? patch + r * ROWB : zrow;
-        aswz[mt] = ok ? swz_of_row<64>(r) : 0;
-      }
-      bf16x8 af[4][MT];
-      if (!(HALO_DBG & 16) || t == 0) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int sl = ks * 2 + khalf;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) af[ks][mt] = *(const bf16x8*)(arow[mt] + ((sl ^ aswz[mt]) << 4));
-        }
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) af[ks][mt] = bcur[ks];
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mt], bcur[ks], acc[mt][0], 0, 0, 0);
-    }
-  }
-  __syncthreads();   // all fragment reads done before the epilogue reuses the patch
-#if (HALO_DBG & 2)
-  {
-    float sum = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) sum += acc[mt][0][j];
-    if (sum == 123.456f) p.y[0] = (bf16)sum;
-    return;
-  }
-#endif
-  conv_epilogue<BM, BN, EPI, false>(p, acc, patch, wid, lane, m0, n0, tile_m, true, nullptr);
-}
-
-template <int EPI>
-static int launch_halo(const ConvArgs& a, hipStream_t stream) {
-  const int patch_rows = (128 + 2 * (a.IW + 1) + 7) & ~7;
-  constexpr size_t EP = 4 * 64 * (32 * 2 + 16) + 2 * 32 * 2 * 4;   // the epilogue's row tiles + statistics exchange
-  const size_t body = (size_t)patch_rows * 128 > EP ? (size_t)patch_rows * 128 : EP;
-  const size_t lds = MAX_TAPS * 4 + 128 + body;
-  static bool attr_set[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  dev = (dev >= 0 && dev < 64) ? dev : 0;
-  if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute((const void*)conv_halo_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    attr_set[dev] = true;
-  }
-  const unsigned mtiles = (a.M + 127) / 128, ntiles = (a.Cout + 63) / 64;
-  hipLaunchKernelGGL((conv_halo_kernel<EPI>), dim3(mtiles * ntiles), dim3(256), lds, stream, a, patch_rows);
-  return (int)hipGetLastError();
-}
-
-// The shapes conv_halo_kernel takes (the caller vouches that every tap offset lies within one pixel).
-static bool halo_ok(const ConvArgs& a) {
-  return a.Cin == 64 && a.T >= 1 && a.T <= 9 && a.K == a.T * 64 && a.isy == 1 && a.isx == 1 && a.osy == 1 && a.osx == 1 &&
-         a.oy0 == 0 && a.ox0 == 0 && a.dense_out && !a.pointwise && a.x2 == nullptr && a.IH == a.OYn && a.IW == a.OXn &&
-         a.IH == a.OH && a.IW == a.OW && a.IW <= 160 && a.tile_m_base == 0 && a.tile_m_count == 0 &&
-         a.stat_row_base == 0 && a.M % (a.IH * a.IW) == 0;
-}
-
-static int launch_halo_epi(const ConvArgs& a, hipStream_t stream) {
-  if (!halo_ok(a)) return -10;
-  if (a.bn_y != nullptr || a.bn_gate_store) return launch_halo<3>(a, stream);
-  if (a.stats != nullptr || a.stat_acc != nullptr) return launch_halo<1>(a, stream);
-  if (a.bias != nullptr || a.relu || a.oscale != nullptr || a.ldo != a.Cout) return launch_halo<2>(a, stream);
-  return launch_halo<0>(a, stream);
-}
+// Same-size 3x3 over 64 input channels with the weights resident on chip and the pixel operand staged once per tile:
+// a persistent kernel of its own (conv_p3.hip).
+int conv_p3_launch(const ConvArgs& a, hipStream_t stream);
 
 // Number of partial-statistics rows the kernel writes for a given M and BM (one per row of tiles; a 256-row
 // macro tile is two 128-row tiles).
@@ -707,7 +523,7 @@ extern "C" int dtfa_conv_igemm(const ConvArgs* a, int bm, int bn, int bk, int ns
 }
 
 // ``ksp`` > 1: the reduction of every tile split over ksp wave groups of one workgroup (the 64 x 64 x 64 tile with two
-// stages: 2 or 4 groups).  ``ksp`` == -1 (with the 128 x 64 x 64 tile): conv_halo_kernel.
+// stages: 2 or 4 groups).  ``ksp`` == -1 (with the 128 x 64 x 64 tile): the persistent 3x3 kernel of conv_p3.hip.
 extern "C" int dtfa_conv_igemm_ks(const ConvArgs* a, int bm, int bn, int bk, int nst, int ksp, hipStream_t stream) {
   return conv_igemm_dispatch(a, bm, bn, bk, nst, ksp, stream);
 }
@@ -751,7 +567,7 @@ static int conv_igemm_dispatch(const ConvArgs* a, int bm, int bn, int bk, int ns
       return -9;
     if (a->tile_m_count > 0 && bm == 256 && (a->tile_m_count & 1)) return -9;   // whole macro tiles
   }
-  if (ksp == -1) return (bm == 128 && bn == 64 && bk == 64) ? launch_halo_epi(*a, stream) : -3;
+  if (ksp == -1) return (bm == 128 && bn == 64 && bk == 64) ? conv_p3_launch(*a, stream) : -3;
   if (ksp != 1) {
     if (bm == 64 && bn == 64 && bk == 64 && nst == 2 && ksp == 2) return launch_conv_epi<64, 64, 64, 2, 1, 2>(*a, stream);
     if (bm == 64 && bn == 64 && bk == 64 && nst == 2 && ksp == 4) return launch_conv_epi<64, 64, 64, 2, 1, 4>(*a, stream);

@@ -391,18 +391,21 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
             found = tune.measure("igemm", key, _igemm_candidates(M, cout, K), launch, rule)
         if found is not None:   # entries measured before the reduction split existed carry no split: the rule adds it
             cfg = found if len(found) > 5 else tuple(found) + (pick_ksplit(found, M, cout, K),)
-    if (_HALO and near_taps and cin == 64 and cout <= 64 and x2 is None and dense_out and iw <= 160
-            and M >= _HALO_MIN_ROWS and not _env_tile("DTFA_CONV_TILE")):
-        cfg = (128, 64, 64, 3, 0, -1)   # conv_halo_kernel: the pixel operand staged once per tile, not once per tap
+    if (_P3 and near_taps and cin == 64 and cout <= 64 and x2 is None and dense_out and iw <= P3_MAX_WIDTH
+            and stat_acc is None and bn_tap is None and M >= _P3_MIN_ROWS and not _env_tile("DTFA_CONV_TILE")):
+        cfg = (128, 64, 64, 3, 0, -1)   # conv_p3_kernel: one workgroup per CU, weights and pixel patches in LDS
     return launch(cfg)
 
 
 # Reduction split inside the workgroup (conv_igemm.hip, KSP): for launches of few tiles -- the small-launch path's
 # 64 x 64 x 64 tile -- with a deep reduction, 2 or 4 wave groups each take a slice of every k-tile.
-# conv_halo_kernel (same-size 3x3 over 64 channels with the pixel operand staged once per tile): bit-exact with the
-# ordinary kernel and no faster on the layers it was written for (profiles/conv_pmc.md, last section): off
-_HALO = os.environ.get("DTFA_CONV_HALO", "0") == "1"
-_HALO_MIN_ROWS = int(os.environ.get("DTFA_CONV_HALO_MIN_ROWS", str(1 << 16)))
+# conv_p3_kernel (csrc/hip/conv_p3.hip: same-size 3x3 over 64 channels by one persistent workgroup per CU, the
+# weights resident in LDS, the pixels a tile touches over all nine taps staged once): same reduction order as the
+# ordinary kernel, so the same bits.  Two pixel patches of 128 + 2 (width + 1) rows must fit in half a CU's LDS.  Not
+# for the data gradient with batch-norm sums (its epilogue needs the registers the resident weights hold).
+_P3 = os.environ.get("DTFA_CONV_P3", "1") == "1"
+_P3_MIN_ROWS = int(os.environ.get("DTFA_CONV_P3_MIN_ROWS", str(1 << 16)))
+P3_MAX_WIDTH = 87
 _KSPLIT = os.environ.get("DTFA_CONV_KSPLIT", "auto")
 _KSPLIT_MAX_TILES = int(os.environ.get("DTFA_CONV_KSPLIT_MAX_TILES", "512"))
 

@@ -245,12 +245,15 @@ def test_reduction_split_inside_the_workgroup(case, ksp, monkeypatch):
     torch.testing.assert_close(got[0].float().cpu(), want, rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("case", [(2, 56, 56, 64, 64), (3, 20, 12, 64, 32), (1, 9, 160, 64, 48), (2, 7, 5, 64, 64)])
-def test_same_size_3x3_with_the_pixel_operand_staged_once(case, monkeypatch):
-    """conv_halo_kernel (3x3, stride 1, 64 input channels: the pixels a tile touches over all nine taps brought into
-    LDS once, taps read at row offsets, out-of-image taps from a zero row) gives the bits of the ordinary kernel --
-    the reduction order is the same -- for the forward with statistics, the folded scale / bias / ReLU epilogue and
-    the data gradient with addend and batch-norm sums."""
+@pytest.mark.parametrize("case", [(2, 56, 56, 64, 64), (3, 20, 12, 64, 32), (1, 9, 87, 64, 48), (2, 7, 5, 64, 64),
+                                  (70, 56, 56, 64, 64)])
+def test_same_size_3x3_by_the_persistent_kernel(case, monkeypatch):
+    """conv_p3_kernel (3x3, stride 1, 64 input channels: one workgroup per CU walks a range of row tiles with the
+    weights resident in LDS; the pixels a tile touches over all nine taps are brought into LDS once, one tile ahead,
+    taps read at row offsets, out-of-image taps from a zero row) gives the bits of the ordinary kernel -- the
+    reduction order is the same -- for the forward with statistics, the folded scale / bias / ReLU epilogue and the
+    data gradient with an addend.  The last case has more tiles than the chip has CUs, so
+    workgroups walk several tiles and both patch buffers are reused."""
     B, H, W, Cin, Cout = case
     full = (B, H, W, Cin, Cout, 3, 3, 1, 1, "SAME")
     x, w, pads = _mk(full, 31)
@@ -277,14 +280,15 @@ def test_same_size_3x3_with_the_pixel_operand_staged_once(case, monkeypatch):
         tap.shift = torch.randn(Cout, generator=gg).cuda() * 0.2
         tap.mask = None
         tap.relu_mode = 2
-        dx = cv.conv_dgrad(dy, wd, dplan, addend=addend, bn_tap=tap)
-        return y, part, z, dx, tap.partials
+        dx = cv.conv_dgrad(dy, wd, dplan, addend=addend, bn_tap=tap)   # (stays with the ordinary kernel)
+        dx0 = cv.conv_dgrad(dy, wd, dplan, addend=addend)
+        return y, part, z, dx, tap.partials, dx0
 
     monkeypatch.setattr(cv.tune, "MODE", "off")
-    monkeypatch.setattr(cv, "_HALO_MIN_ROWS", 0)
-    monkeypatch.setattr(cv, "_HALO", False)
+    monkeypatch.setattr(cv, "_P3_MIN_ROWS", 0)
+    monkeypatch.setattr(cv, "_P3", False)
     want = run()
-    monkeypatch.setattr(cv, "_HALO", True)
+    monkeypatch.setattr(cv, "_P3", True)
     got = run()
     assert cv.pick_fwd_tile(B * H * W, Cout, 576, True)[0] in (64, 128)
     for a, b in zip(got, want):
@@ -292,8 +296,9 @@ def test_same_size_3x3_with_the_pixel_operand_staged_once(case, monkeypatch):
             assert torch.equal(a, b)
         else:   # partial rows: one per 128-row tile here, per tile of the rule's choice there
             torch.testing.assert_close(a.double().sum(0), b.double().sum(0), rtol=1e-5, atol=1e-3)
-    ref_y = ref.conv2d(xb.float().cpu(), wb.float().cpu(), (1, 1), pads)
-    torch.testing.assert_close(got[0].float().cpu(), ref_y, rtol=2e-2, atol=2e-2)
+    if B <= 3:
+        ref_y = ref.conv2d(xb.float().cpu(), wb.float().cpu(), (1, 1), pads)
+        torch.testing.assert_close(got[0].float().cpu(), ref_y, rtol=2e-2, atol=2e-2)
 
 
 def test_dgrad_masked_addend():
