@@ -406,6 +406,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
 _P3 = os.environ.get("DTFA_CONV_P3", "1") == "1"
 _P3_MIN_ROWS = int(os.environ.get("DTFA_CONV_P3_MIN_ROWS", str(1 << 16)))
 P3_MAX_WIDTH = 87
+_P3_DGRAD = os.environ.get("DTFA_CONV_P3_DGRAD", "1") == "1"
 _KSPLIT = os.environ.get("DTFA_CONV_KSPLIT", "auto")
 _KSPLIT_MAX_TILES = int(os.environ.get("DTFA_CONV_KSPLIT_MAX_TILES", "512"))
 
@@ -740,6 +741,20 @@ def dgrad_can_tap(plan: ConvPlan) -> bool:
     output-stride phase otherwise), whose epilogue therefore sees the complete gradient of its pixels: the launches
     can emit the batch-norm backward partial sums of the layer below (their rows simply add up)."""
     return (len(plan.phases) == 1 or (_TAP_PHASES and len(plan.phases) > 1)) and not plan.dgrad_needs_zero
+
+
+def p3_takes(plan: ConvPlan, B: int, cin: int, cout: int) -> bool:
+    """The persistent 3x3 kernel serves a same-size convolution ``cin -> cout`` of this plan's geometry over ``B``
+    images (the forward of the plan, or its data gradient with the channel counts swapped)."""
+    return (_P3 and plan.near_taps and cin == 64 and cout <= 64 and plan.iw <= P3_MAX_WIDTH
+            and B * plan.ih * plan.iw >= _P3_MIN_ROWS and not _env_tile("DTFA_CONV_TILE"))
+
+
+def dgrad_tap_pays(plan: ConvPlan, B: int) -> bool:
+    """Whether the data gradient of ``plan`` should emit the batch-norm backward sums of the layer below in its
+    epilogue.  Not where the persistent 3x3 kernel can run instead: that kernel without the sums plus a separate
+    pass over the gradient (0.55 + 0.33 ms at 56x56x64, batch 2048) beats the ordinary kernel with them (1.18 ms)."""
+    return not (_P3_DGRAD and p3_takes(plan, B, plan.cout, plan.cin))
 
 
 def dgrad_coarse_addend_ok(plan: ConvPlan, stride) -> bool:

@@ -502,7 +502,8 @@ class _ConvBnActFn(Function):
             # expected through the slot has arrived; then the upstream layer's reduction rides along
             tap = links.input_tap
             if tap is not None and not (tap.armed and cv.dgrad_can_tap(plan)
-                                        and (links.input_grad is None or addend is not None)):
+                                        and (links.input_grad is None or addend is not None)
+                                        and (tap.gate_store or cv.dgrad_tap_pays(plan, dy.shape[0]))):
                 tap = None
             gx = cv.conv_dgrad(dy, weight, plan, addend=addend, addend_mask=addend_mask, bn_tap=tap,
                                addend_stride=addend_stride)
