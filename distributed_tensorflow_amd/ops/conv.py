@@ -284,7 +284,7 @@ def pick_wgrad_tile(M: int, cout: int, K: int, cin: int = 0) -> Tuple[int, int, 
     if K != cin or cin <= 0:
         # whole rounds of resident workgroups: a last round that fills a fraction of the slots runs as long as a full
         # one.  Slots per CU follow from the registers and LDS of each instantiation; rounds measured at batch 2048 /
-        # 1024 over the ResNet-50 and flower CNN layers (tools/dev/bench_wgrad_rounds.py): four for the 64 x 64 tile
+        # 1024 over the ResNet-50 and flower CNN layers (tools/experiments/bench_wgrad_rounds.py): four for the 64 x 64 tile
         # (56x56 3x3 64->64: -25 % against 1.3 rounds, 112x112 32->64: -21 % against 3.3), three for 128 x 128
         # (-5 %), and for the 256-wide tiles one round per nine output tiles up to four (-5 .. 13 %)
         per_cu, rounds = _WGRAD_RESIDENT.get((bmw, bnw, bkp), (2, 4))
@@ -419,7 +419,7 @@ def pick_ksplit(tile, M: int, cout: int, K: int) -> int:
     tiles = -(-M // 64) * -(-cout // 64)
     if tiles > _KSPLIT_MAX_TILES:
         return 1
-    # graph-timed at batch 32 (tools/dev/sweep_ksplit.py): up to a workgroup per CU, 8x8 2048->384 17.6 -> 12.5 (two
+    # graph-timed at batch 32 (tools/experiments/sweep_ksplit.py): up to a workgroup per CU, 8x8 2048->384 17.6 -> 12.5 (two
     # groups) -> 11.7 us (four), 8x8 3x3 448->384 (K = 4032) 34.0 -> 22.7 -> 19.8; with 435 tiles (the 17x17 layers)
     # two groups gain 10 % and four, at one 1024-thread workgroup per CU, lose 30 %
     if tiles <= 256:

@@ -98,7 +98,7 @@ def _deliver_small(param, grad: Optional[torch.Tensor]):
 # 65.9 -> 66.0 k img/s for depths 2 .. 16, i.e. within run-to-run noise -- at these sizes every kernel fills
 # the chip by itself and a second stream only fills tile-quantisation tails.  (Pairs of one launch each, side by side:
 # a memory-bound 1x1 data gradient next to a 3x3 weight gradient finishes 3 .. 9 % sooner than the two in a row, two
-# memory-bound launches 11 .. 25 % later -- tools/dev/overlap_probe.py; sending only the 3x3 weight gradients to the
+# memory-bound launches 11 .. 25 % later -- tools/experiments/overlap_probe.py; sending only the 3x3 weight gradients to the
 # side stream still left the whole step unchanged.)  Off by default.
 # The operands of an in-flight weight gradient are kept referenced (not ``record_stream``-ed: blocks marked that
 # way return to the allocator only after an event query, and at tens of GB of activations the allocator then

@@ -32,7 +32,7 @@ def test_forward_backward_matches_cpu_reference(name, size, batch, damp):
     scale).  At 1.0 a random 50-layer network at these sizes is chaotic in bf16: *any* bf16 evaluation -- PyTorch's own
     GPU ops included -- returns gradients uncorrelated with the fp32 ones (relative error 1.3 over the whole gradient),
     and a comparison proves nothing.  Damped, the same comparison is sharp: whole-gradient error 0.09 .. 0.12, loss
-    within 0.002 (tools/dev/diag_model_tol.py prints the calibration)."""
+    within 0.002 (tools/experiments/diag_model_tol.py prints the calibration)."""
     torch.manual_seed(0)
     kw = {"dropout_rate": 0.0} if name == "flower_cnn" else {"zero_init_residual": False}
     cpu = build_model(name, device="cpu", **kw).train()

@@ -1,6 +1,6 @@
 // Standalone timing of conv_p3_kernel on the ResNet-50 56x56 64 -> 64 layer (no framework): prints microseconds per
 // launch for the statistics epilogue and for the data-gradient epilogue with batch-norm sums.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DP3_DBG=n] tools/dev/p3_bench.hip -o /tmp/p3_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DP3_DBG=n] tools/experiments/p3_bench.hip -o /tmp/p3_bench
 #include "../../csrc/hip/conv_p3.hip"
 
 #include <cstdio>
