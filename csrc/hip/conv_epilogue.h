@@ -1,5 +1,5 @@
 // Argument block and output epilogue shared by the implicit-GEMM convolution kernels (conv_igemm.hip,
-// conv_pro.hip): bias / ReLU / batch-norm statistics / residual-gradient add / batch-norm backward sums, with
+// conv_p3.hip): bias / ReLU / batch-norm statistics / residual-gradient add / batch-norm backward sums, with
 // bf16 rows staged through LDS so that global stores are 16 B per lane.
 #pragma once
 #include "common.h"

@@ -557,136 +557,6 @@ def dense_skinny(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
 
 
 # --------------------------------------------------------------------------
-# pointwise GEMM with a fused batch-norm prologue on its pixel operand (csrc/hip/conv_pro.hip)
-# --------------------------------------------------------------------------
-PRO_FWD, PRO_FWD_RES, PRO_BWD_RELU, PRO_BWD_MASK, PRO_BWD_PLAIN = 1, 2, 3, 4, 5
-_PRO = os.environ.get("DTFA_CONV_PRO", "1") == "1"
-_PRO_MIN_ROWS = int(os.environ.get("DTFA_CONV_PRO_MIN_ROWS", str(1 << 16)))
-
-
-def pick_pro_tile(M: int, n: int, K: int, pro: int) -> Tuple[int, int]:
-    """(BN, BK) of the prologue kernel.  k-tiles of 64 channels: every row access is then a whole 128-byte line
-    (with 32 the two halves of a line were fetched by different k-tiles: 4.0 instead of 5.2 TB/s).  Outputs wider than 128 columns take several column tiles: their
-    workgroups run side by side on one XCD (consecutive block ids), so the repeated operand reads are L2 hits;
-    only the first column tile writes the side output."""
-    forced = _env_tile("DTFA_PRO_TILE")
-    if forced:
-        return forced[0], forced[1]
-    return (64, 64) if n <= 64 else (128, 64)
-
-
-def pro_supported(plan: "ConvPlan", B: int, dgrad: bool) -> bool:
-    """The prologue kernel serves 1x1 / stride-1 / unpadded layers at sizes where the elementwise passes are
-    bound by HBM (many rows); small problems keep the separate passes (fewer, better-filled launches)."""
-    return _PRO and plan.is_pointwise and B * plan.oh * plan.ow >= _PRO_MIN_ROWS
-
-
-def conv_pro(a_src: torch.Tensor, w2d: torch.Tensor, n_out: int, pro: int, c0: torch.Tensor, c1: torch.Tensor,
-             c2: Optional[torch.Tensor] = None, src2: Optional[torch.Tensor] = None,
-             gate: Optional[torch.Tensor] = None, gscale: Optional[torch.Tensor] = None,
-             gshift: Optional[torch.Tensor] = None, side: Optional[torch.Tensor] = None,
-             side_mask: Optional[torch.Tensor] = None, relu: bool = False, want_stats: bool = False,
-             addend: Optional[torch.Tensor] = None, addend_mask: Optional[torch.Tensor] = None,
-             bn_tap: Optional["BnBackwardTap"] = None, out: Optional[torch.Tensor] = None):
-    """``out[m][n] = sum_k a[m][k] * w2d[n][k]`` with ``a = prologue(a_src, src2, ...)`` computed on the fly:
-
-    * ``PRO_FWD``       ``a = act(a_src * c0 + c1)``
-    * ``PRO_FWD_RES``   ``a = relu(a_src * c0 + c1 + src2)``
-    * ``PRO_BWD_RELU``  ``g = a_src * (src2 * gscale + gshift > 0)``,  ``a = c0 * g + c1 * src2 + c2``
-    * ``PRO_BWD_MASK``  ``g = a_src`` where the bit of ``gate`` is set,  ``a = c0 * g + c1 * src2 + c2``
-    * ``PRO_BWD_PLAIN`` ``g = a_src``,                                  ``a = c0 * g + c1 * src2 + c2``
-
-    ``a_src`` is ``[..., K]`` bf16 (flattened to rows), coefficients are fp32 ``[K]``.  ``side`` (same shape as
-    ``a_src``) receives ``a``; ``side_mask`` (forward modes with ReLU) one bit per element, ``a > 0``.  The output
-    options are those of the convolution kernel: batch-norm statistics partials (``want_stats``), an addend
-    (optionally bit-gated) and the batch-norm backward sums of the layer below (``bn_tap``).
-    Returns ``(out [..., n_out], partials or None)``."""
-    hipk.require(a_src, torch.bfloat16, "a_src")
-    hipk.require(w2d, torch.bfloat16, "w2d")
-    K = a_src.shape[-1]
-    M = a_src.numel() // K
-    if w2d.numel() != n_out * K or K % 8 or n_out % 8:
-        raise ValueError("prologue GEMM: weight / channel sizes")
-    if M >= 1 << 31:
-        raise ValueError("too many rows for 32-bit row indices")
-    bwd = pro >= PRO_BWD_RELU
-    need = [("c0", c0), ("c1", c1)] + ([("c2", c2)] if bwd else [])
-    if pro == PRO_BWD_RELU:
-        need += [("gscale", gscale), ("gshift", gshift)]
-    for nm, t in need:
-        if t is None:
-            raise ValueError("prologue GEMM: %s missing" % nm)
-        hipk.require(t, torch.float32, nm)
-        if t.numel() != K:
-            raise ValueError("prologue GEMM: %s needs K entries" % nm)
-    if pro != PRO_FWD:
-        if src2 is None:
-            raise ValueError("prologue GEMM: second operand missing")
-        hipk.require(src2, torch.bfloat16, "src2")
-        if src2.shape != a_src.shape:
-            raise ValueError("prologue GEMM: operand shapes differ")
-    if pro == PRO_BWD_MASK:
-        if gate is None or gate.dtype != torch.uint8 or gate.numel() * 8 != a_src.numel() or not gate.is_contiguous():
-            raise ValueError("prologue GEMM: gate bitmask size")
-    if side is not None:
-        hipk.require(side, torch.bfloat16, "side")
-        if side.shape != a_src.shape:
-            raise ValueError("prologue GEMM: side output shape")
-    if side_mask is not None:
-        if bwd or not (relu or pro == PRO_FWD_RES) or side_mask.dtype != torch.uint8 \
-                or side_mask.numel() * 8 != a_src.numel() or not side_mask.is_contiguous():
-            raise ValueError("prologue GEMM: side bitmask")
-    oshape = tuple(a_src.shape[:-1]) + (n_out,)
-    if out is None:
-        out = torch.empty(oshape, dtype=torch.bfloat16, device=a_src.device)
-    else:
-        hipk.require(out, torch.bfloat16, "out")
-        if tuple(out.shape) != oshape:
-            raise ValueError("prologue GEMM: output shape")
-    if addend is not None:
-        hipk.require(addend, torch.bfloat16, "addend")
-        if tuple(addend.shape) != oshape or want_stats:
-            raise ValueError("prologue GEMM: addend shape")
-        if addend_mask is not None and (addend_mask.dtype != torch.uint8 or addend_mask.numel() * 8 != addend.numel()):
-            raise ValueError("prologue GEMM: addend bitmask size")
-    elif addend_mask is not None:
-        raise ValueError("addend_mask without addend")
-    if bn_tap is not None:
-        if want_stats:
-            raise ValueError("prologue GEMM: statistics and batch-norm tap are exclusive")
-        bn_tap.validate(oshape, n_out)
-    L = hipk.lib()
-    bn, bk = pick_pro_tile(M, n_out, K, pro)
-    part = None
-    if want_stats or bn_tap is not None:
-        part = torch.empty((L.dtfa_conv_stats_rows(M, 128), 2, n_out), dtype=torch.float32, device=a_src.device)
-    a = hipk.ConvArgs()
-    a.x, a.w, a.y = a_src.data_ptr(), w2d.data_ptr(), out.data_ptr()
-    a.addend, a.addend_mask = hipk.ptr(addend), hipk.ptr(addend_mask)
-    if bn_tap is not None:
-        a.bn_y, a.bn_mean, a.bn_invstd = bn_tap.y.data_ptr(), bn_tap.mean.data_ptr(), bn_tap.invstd.data_ptr()
-        a.bn_scale, a.bn_shift, a.bn_mask = hipk.ptr(bn_tap.scale), hipk.ptr(bn_tap.shift), hipk.ptr(bn_tap.mask)
-        a.bn_relu = bn_tap.relu_mode
-    a.stats = hipk.ptr(part)
-    a.zero = hipk.zero_page(a_src.device).data_ptr()
-    a.IH, a.IW, a.Cin = 1, 1, K
-    a.OH, a.OW, a.Cout = 1, 1, n_out
-    a.OYn, a.OXn = 1, 1
-    a.osy = a.osx = a.isy = a.isx = 1
-    a.T, a.M, a.K, a.K1 = 1, M, K, K
-    a.cin_magic = _magic(K)
-    a.ldo = n_out
-    a.dense_out = a.pointwise = 1
-    q = hipk.ProArgs()
-    q.src2, q.gate = hipk.ptr(src2), hipk.ptr(gate)
-    q.c0, q.c1, q.c2 = c0.data_ptr(), c1.data_ptr(), hipk.ptr(c2)
-    q.gscale, q.gshift = hipk.ptr(gscale), hipk.ptr(gshift)
-    q.side, q.side_mask = hipk.ptr(side), hipk.ptr(side_mask)
-    q.relu = 1 if relu else 0
-    hipk.check(L.dtfa_conv_pro(C.byref(a), C.byref(q), pro, bn, bk, hipk.stream()), "conv_pro %d %dx%d" % (pro, bn, bk))
-    return out, part
-
-
 class BnBackwardTap:
     """What a data-gradient kernel needs to emit the backward partial sums of the batch-norm layer its
     output flows into: that layer's input ``y`` and statistics, and how its ReLU sign is obtained

@@ -40,13 +40,6 @@ class ConvArgs(C.Structure):
     ]
 
 
-class ProArgs(C.Structure):
-    _fields_ = [
-        ("src2", c_void), ("gate", c_void), ("c0", c_void), ("c1", c_void), ("c2", c_void), ("gscale", c_void),
-        ("gshift", c_void), ("side", c_void), ("side_mask", c_void), ("relu", c_int),
-    ]
-
-
 class WgradArgs(C.Structure):
     _fields_ = [
         ("x", c_void), ("dy", c_void), ("slab", c_void), ("zero", c_void), ("taps", c_void),
@@ -92,7 +85,6 @@ def lib():
 class _Sigs:
     dtfa_conv_igemm = [C.POINTER(ConvArgs), c_int, c_int, c_int, c_int, c_void]
     dtfa_conv_igemm_ks = [C.POINTER(ConvArgs), c_int, c_int, c_int, c_int, c_int, c_void]
-    dtfa_conv_pro = [C.POINTER(ConvArgs), C.POINTER(ProArgs), c_int, c_int, c_int, c_void]
     dtfa_conv_stats_rows = [c_int, c_int]
     dtfa_dense_skinny = [C.POINTER(SkinnyArgs), c_void]
     dtfa_conv_wgrad = [C.POINTER(WgradArgs), c_int, c_int, c_int, c_int, c_void]

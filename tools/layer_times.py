@@ -52,7 +52,7 @@ def min_bytes(args, kw, out) -> int:
 
 
 def flops_of(name, args) -> float:
-    if name in ("conv_fwd", "conv_dgrad", "conv_wgrad", "conv_pro"):
+    if name in ("conv_fwd", "conv_dgrad", "conv_wgrad"):
         plan = next((a for a in args if isinstance(a, cv.ConvPlan)), None)
         t = next((a for a in args if isinstance(a, torch.Tensor)), None)
         if plan is not None and t is not None:
@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--hbm_tbs", type=float, default=5.5, help="achievable HBM rate for the bound column (TB/s)")
     ap.add_argument("--mfma_tfs", type=float, default=2500.0, help="dense bf16 MFMA peak for the bound column (TFLOP/s)")
     args = ap.parse_args()
-    for nm in ("conv_fwd", "conv_dgrad", "conv_wgrad", "conv_pro"):
+    for nm in ("conv_fwd", "conv_dgrad", "conv_wgrad"):
         wrap(cv, nm)
     for nm in ("bn_apply", "bn_finalize", "bn_backward_coefs", "bn_backward_apply", "bn_stats_partials", "mask_mul",
                "bn_relu_maxpool_fwd", "bn_pool_backward", "maxpool_fwd", "maxpool_bwd", "gap_fwd", "gap_bwd", "reduce_partials"):
