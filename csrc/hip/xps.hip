@@ -659,9 +659,10 @@ extern "C" int dtfa_xps_gate(void* ctx, int staleness, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-static unsigned blocks_per_owner(size_t piece, int nown) {
+static unsigned blocks_per_owner(size_t piece, int nown, size_t max_blocks = 1024) {
   size_t b = (piece / 4 + 255) / 256;
-  size_t cap = (size_t)(1024 / nown);
+  size_t cap = max_blocks / (size_t)nown;
+  if (cap == 0) cap = 1;
   if (b > cap) b = cap;
   return (unsigned)(b ? b : 1);
 }
@@ -699,7 +700,9 @@ extern "C" int dtfa_xps_push(void* ctx, const void* grad, hipStream_t st) {
   if (c->widx < 0 || ((uintptr_t)grad) % 16) return -1;
   hipLaunchKernelGGL(xps_push_wait_kernel, dim3(1), dim3(64), 0, st, c->ptrs, c->priv, c->nown, c->widx,
                      ticks_of(c, c->timeout_s));
-  const unsigned bpo = blocks_per_owner(c->piece, c->nown);
+  // (every block ends in a system-scope release, which costs the same whatever the block stored: few, fat blocks)
+  static const size_t push_blocks = getenv("DTFA_XPS_PUSH_BLOCKS") ? (size_t)atoi(getenv("DTFA_XPS_PUSH_BLOCKS")) : 256;
+  const unsigned bpo = blocks_per_owner(c->piece, c->nown, push_blocks);
   if (c->gbytes == 2)
     hipLaunchKernelGGL(xps_push_kernel<bf16>, dim3(bpo * c->nown), dim3(256), 0, st, c->ptrs, c->priv, c->nown, c->widx,
                        c->piece, c->off_mail, (const bf16*)grad, bpo, c->report);
