@@ -47,6 +47,9 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default depends on the model)")
     ap.add_argument("--bucket_mb", type=float, default=0.0,
                     help="gradient bucket size in MiB (0: 32, or a quarter of the gradient for models under 64 MiB)")
+    ap.add_argument("--overlap_gather", type=int, default=1,
+                    help="sharded_ps: 1 = the parameter all-gathers of a step are waited for inside the next forward pass, "
+                         "layer by layer; 0 = at the end of the step")
     ap.add_argument("--staleness", type=int, default=1,
                     help="async_ssp: delay in steps; async_ps: how far a worker may run ahead (-1 = unbounded, 0 = lock step)")
     ap.add_argument("--ps_apply", default="auto", choices=["auto", "per_push", "aggregate"],
@@ -201,7 +204,7 @@ def run_config(args, model_name, batch, device, rank, world, mode=None):
 
         engine = DataParallelEngine(model, mode=mode, optimizer=opt, lr=lr, opt_kwargs=okw,
                                     bucket_mb=args.bucket_mb, staleness=args.staleness, p2p_max_bytes=args.p2p_kb * 1024,
-                                    grad_dtype=grad_dtype)
+                                    grad_dtype=grad_dtype, overlap_gather=bool(args.overlap_gather))
     engine.measure_comm = not args.hip_graph  # (events cannot be timed inside a captured graph)
 
     # synthetic batch generated on the device (a 2048 x 224 x 224 host tensor per rank would cost seconds and GBs)
