@@ -17,7 +17,8 @@ def data(rank, n, dtype, it):
 def main():
     rank, world, port, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    # GPU 0 for every rank, or one GPU per rank where the test asks for it on a box with several
+    torch.cuda.set_device(rank % torch.cuda.device_count() if os.environ.get("DTFA_TEST_DEVICE_PER_RANK") == "1" else 0)
     p2p = P2PAllReduce(max_bytes=1 << 20, timeout_s=2.0 if mode == "timeout" else 20.0)
     if mode == "timeout":
         if rank == 0:

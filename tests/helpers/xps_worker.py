@@ -38,6 +38,14 @@ def step(m, eng, rank, t):
     return loss
 
 
+def _device_of(rank):
+    """Device of a rank process: GPU 0 for everybody (the pool's boxes have one), or one GPU per rank when the test
+    asks for it (``DTFA_TEST_DEVICE_PER_RANK=1`` on a node with several)."""
+    if os.environ.get("DTFA_TEST_DEVICE_PER_RANK") == "1":
+        return rank % torch.cuda.device_count()
+    return 0
+
+
 def masters(eng):
     eng.full_master()
     return torch.cat([g.master[s.offset:s.offset + s.numel].clone().cpu() for g in eng.flat.groups for s in g.segments])
@@ -46,7 +54,7 @@ def masters(eng):
 def ps_cluster_role(rank, world, port, mode, out_dir):
     """ps tasks own the variables: process 0 and 1 are ps tasks, the others workers 0 .. world - 3.  Worker 1 dies
     after two steps without a word; the last worker starts when the others are well under way."""
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(_device_of(rank))
     n_ps, n_workers = 2, world - 2
     cluster = XpsCluster("127.0.0.1", int(port), n_ps, n_workers, connect_timeout=60.0)
     result = {"rank": rank}
@@ -99,7 +107,7 @@ def main():
     if mode == "ps_owned":
         return ps_cluster_role(rank, world, port, mode, out_dir)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(_device_of(rank))
     opt = "momentum" if "momentum" in mode else "adam"
     okw = {"momentum": 0.9, "weight_decay": 1e-3} if opt == "momentum" else {}
     lr = 0.05 if opt == "momentum" else 1e-2

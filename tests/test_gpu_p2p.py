@@ -19,9 +19,10 @@ def _port():
     return str(p)
 
 
-def _launch(mode, world=2):
+def _launch(mode, world=2, device_per_rank=False):
     port = _port()
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, mode], stdout=subprocess.PIPE,
+    env = dict(os.environ, DTFA_TEST_DEVICE_PER_RANK="1" if device_per_rank else "0")
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, mode], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     try:
@@ -50,3 +51,14 @@ def test_p2p_allreduce_three_ranks_one_gpu():
 def test_p2p_allreduce_times_out_without_peer():
     procs, outs = _launch("timeout")
     assert procs[0].returncode == 0 and "TIMEOUT_DETECTED" in outs[0], outs[0][-3000:]
+
+
+@pytest.mark.multigpu
+def test_p2p_allreduce_across_devices():
+    """Every rank on a GPU of its own: mailboxes mapped between different devices, flags and payload over xGMI.
+    Only collected on boxes with two or more GPUs (the pool's test boxes have one: there this path is unpinned)."""
+    import torch
+
+    procs, outs = _launch("run", world=min(4, torch.cuda.device_count()), device_per_rank=True)
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "P2P_OK" in o, o[-3000:]

@@ -20,9 +20,10 @@ def _port():
     return str(p)
 
 
-def _launch(mode, world, out_dir, timeout=170):
+def _launch(mode, world, out_dir, timeout=170, device_per_rank=False):
     port = _port()
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, mode, str(out_dir)],
+    env = dict(os.environ, DTFA_TEST_DEVICE_PER_RANK="1" if device_per_rank else "0")
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, mode, str(out_dir)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     try:
@@ -81,4 +82,22 @@ def test_ps_tasks_own_the_variables_workers_die_and_join_late(tmp_path):
 
 def test_checkpoint_and_restore_through_one_sided_reads(tmp_path):
     procs, outs = _launch("ckpt", 2, tmp_path)
+    _ok(procs, outs)
+
+
+@pytest.mark.multigpu
+def test_across_devices_lockstep_bitwise_and_staleness_bound(tmp_path):
+    """The same protocol with every rank process on a GPU of its own: peer mappings between different devices,
+    system-scope stores and sequence words over xGMI.  Lock-step rounds must still equal synchronous data parallelism
+    bit for bit, and the bounded-staleness run must apply every push once.  Only collected on boxes with two or more
+    GPUs (the pool's test boxes have one: there this path is unpinned)."""
+    a_p, a_o = _launch("lockstep_adam", 2, tmp_path, device_per_rank=True)
+    _ok(a_p, a_o)
+    b_p, b_o = _launch("syncdp_adam", 2, tmp_path, device_per_rank=True)
+    for p, o in zip(b_p, b_o):
+        assert p.returncode == 0, o[-3000:]
+    xa = [torch.load(os.path.join(tmp_path, "xps_lockstep_adam_r%d.pt" % r)) for r in range(2)]
+    sa = [torch.load(os.path.join(tmp_path, "xps_syncdp_adam_r%d.pt" % r)) for r in range(2)]
+    assert torch.equal(xa[0], xa[1]) and torch.equal(xa[0], sa[0])
+    procs, outs = _launch("stale", 3, tmp_path, device_per_rank=True)   # (ranks are dealt over the GPUs there are)
     _ok(procs, outs)
