@@ -65,8 +65,11 @@ def parse_args(argv=None):
     ap.add_argument("--also", default="flower_cnn",
                     help="second model measured after the headline one and reported under \"also\" ('' = none)")
     ap.add_argument("--also_batch", type=int, default=0, help="per-GPU batch of the second model (default: its own)")
-    ap.add_argument("--also_modes", default="sharded_ps,async_ssp,async_ps",
-                    help="distribution modes the headline model is measured in as well, reported under \"also\" ('' = none)")
+    ap.add_argument("--also_modes", default="auto",
+                    help="distribution modes the headline model is measured in as well, reported under \"also\" ('' = none; "
+                         "auto = sharded_ps,async_ssp and, on one GPU, async_ps: across GPUs the GPU-resident parameter "
+                         "server maps peer memory between devices, which no box this tree was tested on has, so there it "
+                         "runs only when named -- as --mode async_ps or in this list -- and cannot cost the headline record)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: rehearse the multi-rank control flow over gloo (not a measurement)")
     ap.add_argument("--image_size", type=int, default=0, help="square image size (default: the model's)")
@@ -295,6 +298,7 @@ ALSO_KEYS = ("value", "ms_per_step", "per_gpu_batch", "global_batch", "first_los
 
 def run_rank(args) -> int:
     import gc
+    import signal
     import threading
 
     import torch
@@ -397,6 +401,17 @@ def run_rank(args) -> int:
 
     if args.also_timeout > 0:
         threading.Thread(target=watchdog, daemon=True).start()
+    if rank == 0 and threading.current_thread() is threading.main_thread():
+        # a launcher that loses another rank during the secondary runs ends this one with SIGTERM: the headline
+        # result is printed first, then the process goes with a failing status
+        def on_term(signum, frame):
+            with report_lock:
+                also.setdefault("error", "terminated during the secondary runs (signal %d)" % signum)
+            report()
+            sys.stdout.flush()
+            os._exit(3)
+
+        signal.signal(signal.SIGTERM, on_term)
     if args.also and args.also != args.model:
         # the second model of the headline metric (flower CNN), same K / W, measured after the headline run
         gc.collect()
@@ -409,7 +424,10 @@ def run_rank(args) -> int:
             put(args.also, {"error": "%s: %s" % (type(e).__name__, e)})
     # the headline model in the other distribution modes (sharded parameter ownership: reduce-scatter + all-gather;
     # staleness-bounded delayed all-reduce; the GPU-resident asynchronous parameter server), same batch, same K / W
-    for other in [m for m in args.also_modes.split(",") if m and m != args.mode and not args.hip_graph]:
+    also_modes = args.also_modes
+    if also_modes == "auto":
+        also_modes = "sharded_ps,async_ssp" + (",async_ps" if world == 1 else "")
+    for other in [m for m in also_modes.split(",") if m and m != args.mode and not args.hip_graph]:
         if other == "async_ps" and device.type != "cuda":
             continue   # (its parameters live in GPU memory)
         gc.collect()
