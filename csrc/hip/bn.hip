@@ -390,11 +390,17 @@ __global__ __launch_bounds__(256) void bn_apply_sums_kernel(const bf16* __restri
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                             float momentum, unsigned nvec, int C, int ldz) {
+                                                             float momentum, unsigned nvec, int C, int ldz, int rep) {
   extern __shared__ float coef[];  // [2][C]
   for (int c = threadIdx.x; c < C; c += 256) {
-    const double mu = sums[c] / (double)count;
-    double var = sums[C + c] / (double)count - mu * mu;
+    // (the accumulators may come in ``rep`` replicas of 2 C values, see ConvArgs::stat_rep)
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rep; ++r) {
+      s1 += sums[(size_t)r * 2 * C + c];
+      s2 += sums[(size_t)r * 2 * C + C + c];
+    }
+    const double mu = s1 / (double)count;
+    double var = s2 / (double)count - mu * mu;
     if (var < 0.0) var = 0.0;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = (gamma ? gamma[c] : 1.f) * is;
@@ -436,8 +442,8 @@ __global__ __launch_bounds__(256) void bn_apply_sums_kernel(const bf16* __restri
 
 extern "C" int dtfa_bn_apply_sums(const void* y, void* z, const double* sums, float count, float eps,
                                   const float* gamma, const float* beta, float* run_mean, float* run_var,
-                                  float momentum, long long M, int C, int ldz, int relu, hipStream_t st) {
-  if (C % 8 || ldz % 8 || ldz < C || C > BN_SUMS_MAX_C) return -1;
+                                  float momentum, long long M, int C, int ldz, int relu, int rep, hipStream_t st) {
+  if (C % 8 || ldz % 8 || ldz < C || C > BN_SUMS_MAX_C || rep < 1 || rep > 64) return -1;
   size_t nvec = (size_t)M * C / 8;
   if (nvec == 0) return 0;
   if (nvec >= (1ull << 31)) return -3;
@@ -447,10 +453,10 @@ extern "C" int dtfa_bn_apply_sums(const void* y, void* z, const double* sums, fl
   const size_t lds = (size_t)2 * C * sizeof(float);
   if (relu)
     hipLaunchKernelGGL((bn_apply_sums_kernel<true, U>), dim3(blocks), dim3(256), lds, st, (const bf16*)y, (bf16*)z, sums,
-                       count, eps, gamma, beta, run_mean, run_var, momentum, (unsigned)nvec, C, ldz);
+                       count, eps, gamma, beta, run_mean, run_var, momentum, (unsigned)nvec, C, ldz, rep);
   else
     hipLaunchKernelGGL((bn_apply_sums_kernel<false, U>), dim3(blocks), dim3(256), lds, st, (const bf16*)y, (bf16*)z, sums,
-                       count, eps, gamma, beta, run_mean, run_var, momentum, (unsigned)nvec, C, ldz);
+                       count, eps, gamma, beta, run_mean, run_var, momentum, (unsigned)nvec, C, ldz, rep);
   return (int)hipGetLastError();
 }
 

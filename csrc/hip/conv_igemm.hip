@@ -533,6 +533,7 @@ static int conv_igemm_dispatch(const ConvArgs* a, int bm, int bn, int bk, int ns
   if ((a->x2 == nullptr && a->K != a->T * a->Cin) || a->K >= (1 << 16)) return -2;
   if ((long long)a->IH * a->IW >= (1ll << 24) || (long long)a->IH * a->IW * a->Cin >= (1ll << 32)) return -2;
   if (a->stats != nullptr && a->bias != nullptr) return -4;
+  if (a->stat_acc != nullptr && (a->stat_rep < 0 || (a->stat_rep & (a->stat_rep - 1)) != 0)) return -4;
   if (a->stat_acc != nullptr && (a->stats != nullptr || a->bias != nullptr || a->relu || a->oscale != nullptr ||
                                  a->addend != nullptr || a->bn_y != nullptr || a->bn_gate_store || a->ldo != a->Cout))
     return -4;

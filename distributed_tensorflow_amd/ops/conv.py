@@ -332,6 +332,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
     a.K1 = T * cin
     a.addend_shy, a.addend_shx = addend_shift
     a.stat_acc = hipk.ptr(stat_acc)
+    a.stat_rep = stat_acc.numel() // (2 * cout) if stat_acc is not None else 0
     a.zero = hipk.zero_page(x.device).data_ptr()
     a.taps = taps.data_ptr()
     a.IH, a.IW, a.Cin = ih, iw, cin
@@ -446,6 +447,20 @@ def _igemm_candidates(M: int, cout: int, K: int):
     return out
 
 
+def stat_replicas(rows: int) -> int:
+    """Replicas of the fp64 statistics accumulators for a layer of ``rows`` output pixels: every 64-row tile of a
+    column adds to the same addresses and those atomics are served one after the other (35x35 at batch 32, 613
+    tiles: 12 us of a 19 us launch), so beyond ~100 tiles per address the tiles are dealt over 2 .. 64 replicas."""
+    tiles = -(-rows // 64)
+    rep = 1
+    while rep < 64 and tiles > _STAT_TILES_PER_REPLICA * rep:
+        rep *= 2
+    return rep
+
+
+_STAT_TILES_PER_REPLICA = int(os.environ.get("DTFA_STAT_TILES_PER_REPLICA", "96"))
+
+
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[torch.Tensor] = None,
              relu: bool = False, want_stats: bool = False, scale: Optional[torch.Tensor] = None,
              out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
@@ -453,9 +468,10 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
              stat_acc: Optional[torch.Tensor] = None):
     """x [B,IH,IW,Cin] bf16, w [Cout,KH,KW,Cin] bf16 -> (y [B,OH,OW,Cout] bf16, stats partials or None).
 
-    ``stat_acc`` (fp64 [2 * Cout], zeroed by the caller; excludes every other epilogue option): the column sums and
-    sums of squares of the output are *added* to it by atomics -- for launches of few tiles, whose consumer
-    (``kernels.bn_apply_sums``) then needs no reduction pass over partial rows.
+    ``stat_acc`` (fp64 [R * 2 * Cout], R a power of two, zeroed by the caller; excludes every other epilogue option):
+    the column sums and sums of squares of the output are *added* to it by atomics -- for launches of few tiles, whose
+    consumer (``kernels.bn_apply_sums``) then needs no reduction pass over partial rows.  Row tile t adds to replica
+    ``t mod R`` (``stat_replicas`` says how many a layer wants: atomics on one address are served one at a time).
 
     Pointwise layers: with ``x2`` ([B,OH,OW,C2] bf16) the reduction runs over ``[x | x2]`` and ``w`` is
     ``[Cout, Cin + C2]`` (two 1x1 convolutions summed in one GEMM).
@@ -497,9 +513,10 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
     if B * plan.oh * plan.ow >= 1 << 31:
         raise ValueError("too many output pixels for 32-bit row indices")
     if stat_acc is not None:
-        if (stat_acc.dtype != torch.float64 or stat_acc.numel() != 2 * plan.cout or not stat_acc.is_contiguous()
-                or stat_acc.device != x.device):
-            raise ValueError("stat_acc must hold 2 * Cout contiguous fp64 values on the input's device")
+        rep = stat_acc.numel() // (2 * plan.cout)
+        if (stat_acc.dtype != torch.float64 or rep < 1 or stat_acc.numel() != rep * 2 * plan.cout or rep & (rep - 1)
+                or rep > 64 or not stat_acc.is_contiguous() or stat_acc.device != x.device):
+            raise ValueError("stat_acc must hold 2^k x 2 * Cout contiguous fp64 values on the input's device")
         if (want_stats or bias is not None or scale is not None or relu or residual is not None or out is not None
                 or mask_out is not None):
             raise ValueError("stat_acc excludes the other epilogue options")

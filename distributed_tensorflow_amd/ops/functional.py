@@ -304,7 +304,7 @@ def run_branches(x: torch.Tensor, jobs) -> None:
 # let the convolution add its column sums to a slice of one zeroed fp64 buffer and the normalisation kernel derive
 # its coefficients from the slice: two launches per layer, and one fill per forward pass.
 STAT_ACC_MAX_ROWS = int(os.environ.get("DTFA_STAT_ACC_MAX_ROWS", str(1 << 16)))
-_STAT_CHUNK = 1 << 16   # fp64 values per buffer (512 KB); Inception-v3 needs ~2 x 17 k
+_STAT_CHUNK = 1 << 17   # fp64 values per buffer (1 MB); Inception-v3 needs ~2 x 17 k, several times that in replicas
 
 
 class _StatScope:
@@ -367,7 +367,7 @@ def _stat_slice(plan, rows: int):
     """An accumulator slice for a layer of ``rows`` output pixels, or None (no scope / too many rows / too wide)."""
     if _stat_scope is None or rows > STAT_ACC_MAX_ROWS or plan.cout > K.BN_SUMS_MAX_C:
         return None
-    return _stat_scope.take(2 * plan.cout)
+    return _stat_scope.take(2 * plan.cout * cv.stat_replicas(rows))
 
 
 def _conv_bn_forward_only(x, weight, gamma, beta, plan, run_mean, run_var, eps, momentum, relu, out):

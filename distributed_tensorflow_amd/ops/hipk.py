@@ -36,7 +36,7 @@ class ConvArgs(C.Structure):
         ("bn_mask", c_void), ("bn_relu", c_int),
         ("ldo", c_int), ("oscale", c_void), ("stream_out", c_int), ("omask", c_void), ("dbias", c_void), ("bn_gate_store", c_int),
         ("x2", c_void), ("K1", c_int), ("addend_shy", c_int), ("addend_shx", c_int), ("stat_acc", c_void),
-        ("tile_m_base", c_int), ("tile_m_count", c_int), ("stat_row_base", c_int),
+        ("tile_m_base", c_int), ("tile_m_count", c_int), ("stat_row_base", c_int), ("stat_rep", c_int),
     ]
 
 
@@ -95,7 +95,7 @@ class _Sigs:
     dtfa_bn_eval_coeffs = [c_int, c_float, c_void, c_void, c_void, c_void, c_void, c_void, c_void]
     dtfa_bn_apply = [c_void, c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_int, c_void]
     dtfa_bn_apply_sums = [c_void, c_void, c_void, c_float, c_float, c_void, c_void, c_void, c_void, c_float, c_ll, c_int,
-                          c_int, c_int, c_void]
+                          c_int, c_int, c_int, c_void]
     dtfa_col_partials_rows = [c_ll, c_int]
     dtfa_bn_stats_partials = [c_void, c_void, c_ll, c_int, c_void]
     dtfa_bn_bwd_partials = [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_ll, c_int, c_int, c_void]

@@ -208,11 +208,14 @@ def bn_apply_sums(y: torch.Tensor, sums: torch.Tensor, count: int, eps: float, g
                   momentum: float, relu: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``act(bn(y))`` with batch statistics given as fp64 column sums ``sums`` = [sum y | sum y^2] (2C values, as the
     convolution's statistics epilogue accumulates them): coefficients, running-statistics update and the elementwise
-    pass in one launch.  ``out`` may be a channel slice of a wider NHWC tensor."""
+    pass in one launch.  ``out`` may be a channel slice of a wider NHWC tensor.  ``sums`` may hold several replicas of the
+    2C values (``conv.stat_replicas``), which the kernel adds up."""
     hipk.require(y, BF16, "y")
     M, Cc = _as2d(y)
-    if sums.dtype != torch.float64 or sums.numel() != 2 * Cc or not sums.is_contiguous() or Cc > BN_SUMS_MAX_C:
-        raise ValueError("column sums must be %d contiguous fp64 values" % (2 * Cc))
+    rep = sums.numel() // (2 * Cc) if Cc else 0
+    if (sums.dtype != torch.float64 or rep < 1 or sums.numel() != rep * 2 * Cc or rep & (rep - 1) or rep > 64
+            or not sums.is_contiguous() or Cc > BN_SUMS_MAX_C):
+        raise ValueError("column sums must be 2^k x %d contiguous fp64 values" % (2 * Cc))
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (run_mean, "running_mean"), (run_var, "running_var")):
         if t is not None:
             hipk.require(t, F32, nm)
@@ -224,7 +227,7 @@ def bn_apply_sums(y: torch.Tensor, sums: torch.Tensor, count: int, eps: float, g
         z, ldz = out, channel_slice_pitch(out, y)
     hipk.check(hipk.lib().dtfa_bn_apply_sums(y.data_ptr(), z.data_ptr(), sums.data_ptr(), float(count), float(eps),
                                              hipk.ptr(gamma), hipk.ptr(beta), hipk.ptr(run_mean), hipk.ptr(run_var),
-                                             float(momentum), M, Cc, ldz, 1 if relu else 0, hipk.stream()),
+                                             float(momentum), M, Cc, ldz, 1 if relu else 0, rep, hipk.stream()),
                "bn_apply_sums")
     return z
 

@@ -414,6 +414,26 @@ def test_statistics_accumulated_by_atomics_match_partial_rows(case):
     torch.testing.assert_close(acc, 2 * want, rtol=1e-6, atol=2e-4)
     with pytest.raises(ValueError):
         cv.conv_fwd(xb, wb, plan, stat_acc=acc, want_stats=True)
+    # replicas: row tile t adds to replica t mod R; the replicas add up to the same sums, and the normalisation
+    # kernel that consumes them gives the bits it gives from a single accumulator
+    from distributed_tensorflow_amd.ops import kernels as K
+
+    rep = 8
+    accr = torch.zeros(rep * 2 * Cout, dtype=torch.float64, device="cuda")
+    y2, _ = cv.conv_fwd(xb, wb, plan, stat_acc=accr)
+    assert torch.equal(y2, y0)
+    torch.testing.assert_close(accr.view(rep, -1).sum(0), want, rtol=1e-6, atol=1e-4)
+    if (B * plan.oh * plan.ow + 63) // 64 >= rep:
+        assert (accr.view(rep, -1).abs().sum(1) > 0).all()
+    acc1 = torch.zeros(2 * Cout, dtype=torch.float64, device="cuda")
+    cv.conv_fwd(xb, wb, plan, stat_acc=acc1)
+    rows = B * plan.oh * plan.ow
+    beta = torch.linspace(-1, 1, Cout, device="cuda")
+    z1 = K.bn_apply_sums(y0, acc1, rows, 1e-3, None, beta, None, None, 0.1, True)
+    zr = K.bn_apply_sums(y0, accr, rows, 1e-3, None, beta, None, None, 0.1, True)
+    torch.testing.assert_close(zr.float(), z1.float(), rtol=0, atol=2e-2)   # (sums of fp64 atomics in another order)
+    assert (zr.float() - z1.float()).abs().gt(0).float().mean().item() < 1e-3
+    assert cv.stat_replicas(32 * 35 * 35) == 8 and cv.stat_replicas(32 * 17 * 17) == 2 and cv.stat_replicas(64) == 1
 
 
 @pytest.mark.parametrize("M,N,K,relu,bias", [(32, 1024, 2048, True, True), (1, 8, 1024, False, True), (5, 40, 48, True, False),
