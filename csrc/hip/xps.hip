@@ -23,7 +23,8 @@
 //          (lock step) -- and publishes a new parameter version;
 //   pull   a worker reads the current version of every shard directly from its region;
 //   gate   a worker whose clock is more than `staleness` steps ahead of the slowest live worker waits, reading the
-//          workers' clock words (kept in region 0); a worker that does not move for `timeout` stops counting.
+//          workers' clock words (kept in region 0); a worker that does not move for `timeout` stops counting -- unless
+//          it sits in a bounded wait of its own, which its beat word shows (see `beat`).
 //
 // Region: [0, 512) control words (XpsCtrl) | 2 x piece fp32 parameter versions (buffer v & 1) | nslot x piece fp32
 // optimizer slots | nwrk x 2 x piece gradients (fp32 or bf16): [worker][push parity].
@@ -55,6 +56,7 @@ struct XpsCtrl {
   unsigned wjoined[XPS_MAX_W];   // region 0 only: worker w has joined at some time
   unsigned seq_in[XPS_MAX_W];    // [worker]: gradient pushes completed by that worker
   unsigned seq_done[XPS_MAX_W];  // [worker]: pushes of that worker consumed
+  unsigned wbeat[XPS_MAX_W];     // region 0 only: keeps changing while worker w sits in one of its own bounded waits
 };
 static_assert(sizeof(XpsCtrl) <= XPS_CTRL_BYTES, "control block");
 
@@ -99,6 +101,42 @@ __device__ __forceinline__ void st_sys(unsigned* p, unsigned v) {
 }
 __device__ __forceinline__ XpsCtrl* ctrl_of(const XpsPtrs& P, int o) { return (XpsCtrl*)P.base[o]; }
 
+// Telling "waiting" from "gone".  A process that sits in one of its bounded waits (gate, full mailbox slot, a round's
+// missing push) keeps changing its beat word; a process waiting for THAT process restarts its timer whenever the word
+// has changed, up to XPS_WAIT_CAP timeouts in all.  Without this, two survivors of a dead third write each other off
+// in turn: each one's wait for the dead process lasts exactly as long as the other's patience with it.
+#define XPS_WAIT_CAP 4
+__device__ __forceinline__ void beat(XpsCtrl* c0, int widx, unsigned it) {
+  if (widx >= 0 && (it & 15u) == 0u)
+    __hip_atomic_store(&c0->wbeat[widx], (unsigned)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct PeerWait {
+  long long t_start, t0;
+  unsigned last;
+};
+__device__ __forceinline__ PeerWait begin_wait(const XpsCtrl* c0, int peer) {
+  PeerWait w;
+  w.t_start = w.t0 = wall_clock64();
+  w.last = peer >= 0 ? ld_sys(&c0->wbeat[peer]) : 0u;
+  return w;
+}
+// ``peer`` < 0: nobody's beat to watch (an owner-only process never waits for anybody), the plain timeout.
+__device__ __forceinline__ bool peer_timed_out(PeerWait& w, const XpsCtrl* c0, int peer, long long timeout_ticks) {
+  const long long now = wall_clock64();
+  if (peer >= 0) {
+    const unsigned b = ld_sys(&c0->wbeat[peer]);
+    if (b != w.last) {
+      w.last = b;
+      w.t0 = now;
+    }
+  }
+  return now - w.t0 > timeout_ticks || now - w.t_start > XPS_WAIT_CAP * timeout_ticks;
+}
+// Written off, and its clock has not moved since.
+__device__ __forceinline__ bool known_dead(const XpsPriv* pv, const XpsCtrl* c0, int j) {
+  return pv->dead[j] && ld_sys(&c0->wclock[j]) == pv->dead_clock[j];
+}
+
 // A worker counts for a bound while it has joined, is not done and is not written off.  A written-off worker whose
 // clock has moved since is alive again.
 __device__ __forceinline__ bool worker_counts(XpsPriv* pv, const XpsCtrl* c0, int j, unsigned cj) {
@@ -142,15 +180,16 @@ __global__ __launch_bounds__(64) void xps_gate_kernel(XpsPtrs P, XpsPriv* pv, in
                                                       long long timeout_ticks) {
   const int j = threadIdx.x;
   if (j >= nwrk || j == widx) return;
-  const XpsCtrl* c0 = ctrl_of(P, 0);
+  XpsCtrl* c0 = ctrl_of(P, 0);
   const unsigned my = ld_sys(&c0->wclock[widx]);
-  const long long t0 = wall_clock64();
-  for (;;) {
+  PeerWait w = begin_wait(c0, j);
+  for (unsigned it = 0;; ++it) {
     const unsigned cj = ld_sys(&c0->wclock[j]);
     if (!worker_counts(pv, c0, j, cj)) return;
     if ((int)(my - cj) <= staleness) return;
     __builtin_amdgcn_s_sleep(32);
-    if (wall_clock64() - t0 > timeout_ticks) {
+    beat(c0, widx, it);
+    if (peer_timed_out(w, c0, j, timeout_ticks)) {
       pv->dead[j] = 1;
       pv->dead_clock[j] = cj;
       atomicOr(&pv->status, 1u);
@@ -215,20 +254,37 @@ __global__ __launch_bounds__(256) void xps_pull_kernel(XpsPtrs P, XpsPriv* pv, i
 // once (dropped, counted) until its slot is free again -- which it becomes as soon as somebody applies the region,
 // e.g. the process that takes it over.
 __global__ __launch_bounds__(64) void xps_push_wait_kernel(XpsPtrs P, XpsPriv* pv, int nown, int widx,
-                                                           long long timeout_ticks) {
+                                                           int owners_are_workers, long long timeout_ticks) {
   const int o = threadIdx.x;
   if (o >= nown) return;
   const unsigned k = pv->push_seq + 1u;
   pv->skip[o] = 0;
   if (k <= XPS_SLOTS) return;
+  XpsCtrl* c0 = ctrl_of(P, 0);
   const XpsCtrl* c = ctrl_of(P, o);
-  const long long t0 = wall_clock64();
-  while ((int)(ld_sys(&c->seq_done[widx]) - (k - XPS_SLOTS)) < 0) {
-    bool give_up = pv->odead[o] != 0;
+  PeerWait w = begin_wait(c0, -1);
+  int watched = -1;
+  for (unsigned it = 0; (int)(ld_sys(&c->seq_done[widx]) - (k - XPS_SLOTS)) < 0; ++it) {
+    // who is to free the slot: the region's own process or whoever has taken the region over (where the owners are
+    // the workers; an owner-only process has no beat and is simply given the timeout)
+    const unsigned a = ld_sys(&c->adopter);
+    int applier = owners_are_workers ? (a ? (int)a - 1 : o) : -1;
+    if (applier == widx) applier = -1;
+    if (applier != watched) {
+      watched = applier;
+      w.last = applier >= 0 ? ld_sys(&c0->wbeat[applier]) : 0u;
+    }
+    // (a process the gate has already written off is not waited for a second time)
+    bool give_up = pv->odead[o] != 0 || (applier >= 0 && known_dead(pv, c0, applier));
     if (!give_up) {
       __builtin_amdgcn_s_sleep(32);
-      if (wall_clock64() - t0 > timeout_ticks) {
+      beat(c0, widx, it);
+      if (peer_timed_out(w, c0, applier, timeout_ticks)) {
         pv->odead[o] = 1;
+        if (applier >= 0) {   // ... nor does the gate wait for a process that let a slot time out
+          pv->dead_clock[applier] = ld_sys(&c0->wclock[applier]);
+          pv->dead[applier] = 1;
+        }
         atomicAdd(&pv->timeouts, 1u);
         atomicOr(&pv->status, 1u);
         give_up = true;
@@ -296,7 +352,7 @@ __device__ __forceinline__ bool proc_alive(const XpsPtrs& P, const XpsPriv* pv, 
 //                  index order, oldest first.  No waiting -- except with wait_any (the serving loop of an
 //                  owner-only process), which sleeps up to `idle_ticks` until something has arrived.
 __global__ __launch_bounds__(64) void xps_collect_kernel(XpsPtrs P, XpsPriv* pv, int nown, int nwrk, int self,
-                                                         int adopt_others, int aggregate, int wait_any,
+                                                         int widx, int adopt_others, int aggregate, int wait_any,
                                                          long long timeout_ticks, long long idle_ticks) {
   const int o = blockIdx.x;
   XpsCtrl* R = ctrl_of(P, o);
@@ -354,12 +410,13 @@ __global__ __launch_bounds__(64) void xps_collect_kernel(XpsPtrs P, XpsPriv* pv,
     unsigned in = ld_sys(&R->seq_in[j]);
     if (aggregate) {
       const unsigned need = R->seq_done[j] + 1u;
-      const long long t0 = wall_clock64();
+      PeerWait w = begin_wait(c0, j == widx ? -1 : j);
       bool counts = true;
-      while ((int)(in - need) < 0) {
+      for (unsigned it = 0; (int)(in - need) < 0; ++it) {
         if (!worker_counts(pv, c0, j, ld_sys(&c0->wclock[j]))) { counts = false; break; }
         __builtin_amdgcn_s_sleep(32);
-        if (wall_clock64() - t0 > timeout_ticks) {
+        beat(ctrl_of(P, 0), widx, it);
+        if (peer_timed_out(w, c0, j == widx ? -1 : j, timeout_ticks)) {
           pv->dead[j] = 1;
           pv->dead_clock[j] = ld_sys(&c0->wclock[j]);
           atomicOr(&pv->status, 1u);
@@ -699,7 +756,7 @@ extern "C" int dtfa_xps_push(void* ctx, const void* grad, hipStream_t st) {
   if (!connected(c)) return -2;
   if (c->widx < 0 || ((uintptr_t)grad) % 16) return -1;
   hipLaunchKernelGGL(xps_push_wait_kernel, dim3(1), dim3(64), 0, st, c->ptrs, c->priv, c->nown, c->widx,
-                     ticks_of(c, c->timeout_s));
+                     (c->oidx >= 0 && c->widx >= 0) ? 1 : 0, ticks_of(c, c->timeout_s));
   // (every block ends in a system-scope release, which costs the same whatever the block stored: few, fat blocks)
   static const size_t push_blocks = getenv("DTFA_XPS_PUSH_BLOCKS") ? (size_t)atoi(getenv("DTFA_XPS_PUSH_BLOCKS")) : 256;
   const unsigned bpo = blocks_per_owner(c->piece, c->nown, push_blocks);
@@ -730,7 +787,7 @@ extern "C" int dtfa_xps_apply(void* ctx, int kind, float b1, float b2, float eps
     // one workgroup per region; without adopt_others only the own region's does anything
     const int self = c->oidx;
     hipLaunchKernelGGL(xps_collect_kernel, dim3(c->nown), dim3(64), 0, st, c->ptrs, c->priv, c->nown, c->nwrk, self,
-                       adopt_others, aggregate, wait_any, ticks_of(c, c->timeout_s), ticks_of(c, idle_s));
+                       c->widx, adopt_others, aggregate, wait_any, ticks_of(c, c->timeout_s), ticks_of(c, idle_s));
     size_t b = (c->piece / 4 + 255) / 256;
     if (b > 1024) b = 1024;
     const unsigned bpr = (unsigned)b;

@@ -18,7 +18,9 @@ the data path: the variables live in GPU memory that every process maps through 
 * **pull**: a worker reads the current version of every shard straight out of its region;
 * **bounded staleness**: a worker whose clock is more than ``staleness`` steps ahead of the slowest live
   worker waits on the workers' clock words (``-1`` = unbounded, ``0`` = lock step); a worker that does not move
-  for ``timeout`` seconds, or has left, stops counting.
+  for ``timeout`` seconds, or has left, stops counting.  A process that is itself inside such a bounded wait keeps
+  changing a *beat* word, and whoever waits for that process restarts its timer on every change (up to four timeouts
+  in all): the survivors of a dead process do not write each other off while each of them waits for it.
 
 Two deployments:
 
@@ -34,7 +36,9 @@ the lowest-ranked live process takes it over *in place* (compare-and-swap on the
 collect / apply / commit with its own kernels through the peer mapping): every shard keeps training, pushers and
 pullers notice nothing.  Gradients pushed to a dead owner between its death and the take-over wait in their
 mailbox slots; a worker whose slot in that region stays full for a whole ``timeout`` drops that shard of its
-gradient (counted in ``dropped_pushes``) instead of blocking.
+gradient (counted in ``dropped_pushes``) instead of blocking.  Whichever wait notices the dead process first (the
+staleness gate or the full slot) writes it off for the other one too, so a survivor pays one timeout and drops one
+shard of one gradient per dead process.
 
 All device work of a step is kernels on the current stream that read their sequence numbers from device
 memory, so a step is the same launch sequence every time (HIP-graph capturable).  Nothing here uses a collective

@@ -200,7 +200,10 @@ def main():
         assert st["clock"] == 12, st
         assert st["dead_mask"] == 1 << (world - 1), st
         slow = [x for x in t_steps if x > 1.0]
-        assert len(slow) <= 3, t_steps  # the gate and the full mailbox slot of the dead owner ran into the timeout once each
+        assert len(slow) <= 3, t_steps  # one timeout of its own, and the wait for the other survivor's
+        # (whichever wait notices the dead process first writes it off for the other one; the survivors see each
+        # other's beat and do not write each other off)
+        assert st["timeouts"] <= 2 and st["dropped_pushes"] <= 2, st
         # the dead worker's shard was taken over by rank 0 and kept training like the others
         assert st["adopters"][world - 1] == 1, st
         assert (st["adopted_mask"] != 0) == (rank == 0), st
