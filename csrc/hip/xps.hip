@@ -75,7 +75,9 @@ struct XpsPriv {
   unsigned odead[XPS_MAX_O];       // regions whose mailbox slot stayed full for a whole timeout
   unsigned skip[XPS_MAX_O];        // push: regions whose mailbox slot is not free (gradient dropped)
   XpsPlan plan[XPS_MAX_O];         // apply: what to consume, per region
-  unsigned push_seq;               // pushes this worker has made
+  unsigned push_seq;               // pushes this worker has made (dropped ones included)
+  unsigned oseq[XPS_MAX_O];        // pushes of this worker that ARRIVED in region o: a region's numbering has no gaps, so
+                                   // "push k reuses the slot of push k - 2" holds whatever was dropped on the way
   unsigned block_counter;          // last-block detection of the push kernel
   unsigned status;                 // bit 0: a peer timed out, bit 1: push dropped, bit 2: torn pull kept, bit 3: took a region over
   unsigned torn_pulls, dropped_pushes, timeouts, adopted_mask;
@@ -156,7 +158,10 @@ __global__ __launch_bounds__(64) void xps_join_kernel(XpsPtrs P, XpsPriv* pv, in
   const int j = threadIdx.x;
   unsigned cj = 0xffffffffu, sq = 0;
   if (j < nwrk && j != widx && ld_sys(&c0->wjoined[j]) && !ld_sys(&c0->wdone[j])) cj = ld_sys(&c0->wclock[j]);
-  if (j < nown) sq = ld_sys(&ctrl_of(P, j)->seq_in[widx]);
+  if (j < nown) {
+    sq = ld_sys(&ctrl_of(P, j)->seq_in[widx]);
+    pv->oseq[j] = sq;
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     cj = min(cj, (unsigned)__shfl_xor((int)cj, off, 64));
@@ -249,7 +254,8 @@ __global__ __launch_bounds__(256) void xps_pull_kernel(XpsPtrs P, XpsPriv* pv, i
 }
 
 // ---------------------------------------------------------------------------------------------------- push
-// Before a push: lane o waits until this worker's push k - 2 (the slot push k reuses) has been consumed in region o.
+// Before a push: lane o waits until this worker's push k - 2 to region o (the slot push k reuses; k counts the pushes
+// that arrived in THAT region) has been consumed there.
 // A region whose slot stays full for a whole timeout is written off: this push and the following ones skip it at
 // once (dropped, counted) until its slot is free again -- which it becomes as soon as somebody applies the region,
 // e.g. the process that takes it over.
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(64) void xps_push_wait_kernel(XpsPtrs P, XpsPriv* p
                                                            int owners_are_workers, long long timeout_ticks) {
   const int o = threadIdx.x;
   if (o >= nown) return;
-  const unsigned k = pv->push_seq + 1u;
+  const unsigned k = pv->oseq[o] + 1u;
   pv->skip[o] = 0;
   if (k <= XPS_SLOTS) return;
   XpsCtrl* c0 = ctrl_of(P, 0);
@@ -306,8 +312,8 @@ __global__ __launch_bounds__(256) void xps_push_kernel(XpsPtrs P, XpsPriv* pv, i
                                                        unsigned blocks_per_owner, XpsReport* report) {
   const int o = blockIdx.x / blocks_per_owner;
   const unsigned b = blockIdx.x % blocks_per_owner;
-  const unsigned k = pv->push_seq + 1u;
   if (o < nown && !pv->skip[o]) {
+    const unsigned k = pv->oseq[o] + 1u;
     constexpr int VE = 16 / sizeof(G);  // elements per 16-byte vector
     const size_t nvec = piece / VE;
     G* dst = (G*)(P.base[o] + off_mail) + ((size_t)widx * XPS_SLOTS + (k & 1u)) * piece;
@@ -324,10 +330,14 @@ __global__ __launch_bounds__(256) void xps_push_kernel(XpsPtrs P, XpsPriv* pv, i
   __syncthreads();
   if (!last) return;
   __threadfence_system();
-  if (threadIdx.x < (unsigned)nown && !pv->skip[threadIdx.x]) st_sys(&ctrl_of(P, threadIdx.x)->seq_in[widx], k);
+  if (threadIdx.x < (unsigned)nown && !pv->skip[threadIdx.x]) {
+    const unsigned k = pv->oseq[threadIdx.x] + 1u;
+    st_sys(&ctrl_of(P, threadIdx.x)->seq_in[widx], k);
+    pv->oseq[threadIdx.x] = k;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    pv->push_seq = k;
+    pv->push_seq = pv->push_seq + 1u;
     pv->block_counter = 0;
     st_sys(&report->status, pv->status);
   }
