@@ -68,6 +68,13 @@ struct ConvArgs {
 };
 
 #define MAX_TAPS 64
+// Bytes added to the pitch of the epilogue's bf16 staging rows (see conv_epilogue).  With 0 the readback of a wave
+// (64 lanes x 16 bytes) is one contiguous kilobyte, conflict-free for the lane groups of ds_read_b128, with 16 three of
+// every sixteen lanes share a bank pair with another -- and the ResNet-50 step takes the same time either way (16 943 /
+// 16 951 against 16 955 / 16 940 img/s, alternating on one box): these kernels wait for memory, not for LDS.
+#ifndef EP_PAD
+#define EP_PAD 16
+#endif
 
 template <int BK>
 __device__ __forceinline__ int swz_of_row(int row) {
@@ -203,7 +210,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
                                               const EpiPrefetch<BM, BN>* pre = nullptr) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 32, NT = WN / 32;
-  constexpr int EP_PITCH = WN * 2 + 16;
+  constexpr int EP_PITCH = WN * 2 + EP_PAD;
   const int wr = w4 >> 1, wc = w4 & 1;
   const int wid = w4;
   const int khalf = lane >> 5;

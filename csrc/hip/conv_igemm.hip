@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256 * WG * KSP, (KSP > 1 ? 1 : WG == 2 ? (BN > 128 
   // WG = 2: [A of group 0][A of group 1][B];  KSP > 1: [A slice 0] .. [A slice KSP-1][B slice 0] .. [B slice KSP-1]
   constexpr int STAGE = KSP > 1 ? KSP * (BM + BN) * ROWB : (WG * BM + BN) * ROWB;
   constexpr int NBW = NB / WG;                   // weight-tile loads per wave
-  constexpr int EP = 4 * (BM / 2) * ((BN / 2) * 2 + 16) + 2 * (BN / 2) * 2 * 4;  // epilogue bytes per group
+  constexpr int EP = 4 * (BM / 2) * ((BN / 2) * 2 + EP_PAD) + 2 * (BN / 2) * 2 * 4;  // epilogue bytes per group
   constexpr int BOFF = (KSP > 1 ? KSP : WG) * BM * ROWB;   // start of the weight rows inside a stage
   static_assert(NA >= 1 && NBW >= 1 && NB % WG == 0, "tile too small for this staging");
 
@@ -476,7 +476,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   constexpr int ROWB = BK * 2;
   constexpr int STAGE = KSP > 1 ? KSP * (BM + BN) * ROWB : (WG * BM + BN) * ROWB;
   // row tiles + statistics exchange per group (+ the accumulator exchange of a split reduction)
-  constexpr int EP = WG * KSP * (4 * (BM / 2) * ((BN / 2) * 2 + 16) + 2 * (BN / 2) * 2 * 4) + (KSP > 1 ? BM * BN * 4 : 0);
+  constexpr int EP = WG * KSP * (4 * (BM / 2) * ((BN / 2) * 2 + EP_PAD) + 2 * (BN / 2) * 2 * 4) + (KSP > 1 ? BM * BN * 4 : 0);
   size_t lds = MAX_TAPS * 4 + (size_t)((NST * STAGE > EP) ? NST * STAGE : EP);
   unsigned mtiles = a.tile_m_count > 0 ? (unsigned)a.tile_m_count : (a.M + BM - 1) / BM - a.tile_m_base;
   unsigned ntiles = (a.Cout + BN - 1) / BN;

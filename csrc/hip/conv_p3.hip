@@ -33,7 +33,7 @@
 namespace {
 
 constexpr int P3_BM = 128, P3_BN = 64, P3_CIN = 64, P3_ROWB = 128;
-constexpr int P3_EP = 4 * 64 * (32 * 2 + 16) + 2 * 32 * 2 * 4;           // epilogue row tiles + statistics exchange
+constexpr int P3_EP = 4 * 64 * (32 * 2 + EP_PAD) + 2 * 32 * 2 * 4;           // epilogue row tiles + statistics exchange
 constexpr int P3_HEAD = MAX_TAPS * 4 + 128;                              // (unused words) + a pixel row of zeros
 
 // LDS-DMA of 16 bytes per lane from a wave-uniform base plus a 32-bit lane offset to lds_dst + lane * 16 (not seen by
