@@ -59,13 +59,18 @@ __device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
 // ONES: the launch also produces the column sums of its X operand over the pixels, sum_m X[m][n] -- one more MFMA
 // per fragment column with an all-ones row operand held in registers, in the waves of the first row of tiles.  The
 // moments a folded batch-norm needs of a tensor (x^T x and x^T 1) then come from one pass over it.
-template <int BMW, int BNW, int BKP, bool ONES = false>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+// NW: waves per workgroup, 4 (2 x 2) or 8 (2 rows x 4 columns of waves: the 256 x 256 tile, each wave 128 x 64 as in the
+// 256 x 128 tile, a third fewer operand bytes through L2 -> LDS per FLOP, one workgroup per CU).
+template <int BMW, int BNW, int BKP, bool ONES = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int RBA = BMW * 2, RBB = BNW * 2;       // row bytes
   constexpr int CPRA = RBA / 16, CPRB = RBB / 16;   // 16-byte chunks per row
   constexpr int RPIA = 64 / CPRA, RPIB = 64 / CPRB; // rows per wave-instruction
-  constexpr int NA = BKP / (4 * RPIA), NB = BKP / (4 * RPIB);
-  constexpr int WM = BMW / 2, WN = BNW / 2;
+  constexpr int NA = BKP / (NW * RPIA), NB = BKP / (NW * RPIB);
+  constexpr int WCOLS = NW / 2;                     // waves side by side
+  constexpr int WM = BMW / 2, WN = BNW / WCOLS;
+  static_assert(NW == 4 || NW == 8, "four or eight waves");
+  static_assert((NW * RPIA) % 4 == 0 && (NW * RPIB) % 4 == 0, "the staging swizzle repeats every instruction round");
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int KS = BKP / 16;
   constexpr int STAGE = BKP * (RBA + RBB);
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 1, wc = wid & 1;
+  const int wr = wid / WCOLS, wc = wid % WCOLS;
 
   // 1-D grid ordered so that all output tiles of one pixel split share blockIdx % 8, i.e. (under the
   // round-robin block->XCD dispatch) one XCD and its L2: they re-read the same dY / X rows.
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 
   // ---- A' (dY) staging rows ----
   const int a_row = lane / CPRA;                                 // row within instruction
-  // logical chunk: tile row of instruction i is (i * 4 + wid) * RPIA + a_row, and 4 * RPIA rows repeat the swizzle
+  // logical chunk: tile row of instruction i is (i * NW + wid) * RPIA + a_row, and NW * RPIA rows repeat the swizzle
   const int a_chunk = (lane % CPRA) ^ wswz<RBA>(wid * RPIA + a_row);
   const int a_co = co0 + a_chunk * 8;
   const bool a_ok = a_co < p.Cout;
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   int boy[NB], box[NB], bpix[NB], bm[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    int m = kt_begin * BKP + (i * 4 + wid) * RPIB + b_row;
+    int m = kt_begin * BKP + (i * NW + wid) * RPIB + b_row;
     bm[i] = m;
     int b = m / opix;
     int rem = m - b * opix;
@@ -138,16 +143,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     char* sb = sa + BKP * RBA;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      int m = kt * BKP + (i * 4 + wid) * RPIA + a_row;
+      int m = kt * BKP + (i * NW + wid) * RPIA + a_row;
       const bf16* src = (a_ok && m < p.M) ? p.dy + (size_t)m * p.Cout + a_co : p.zero;
-      glds16_untracked(src, sa + (i * 4 + wid) * 1024);
+      glds16_untracked(src, sa + (i * NW + wid) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       int iy = boy[i] * p.isy + b_dy, ix = box[i] * p.isx + b_dx;
       bool ok = b_kok && bm[i] < p.M && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
       const bf16* src = ok ? p.x + ((size_t)(bpix[i] + iy * p.IW + ix) * p.Cin + b_ci) : p.zero;
-      glds16_untracked(src, sb + (i * 4 + wid) * 1024);
+      glds16_untracked(src, sb + (i * NW + wid) * 1024);
       // advance this row by one k-tile (BKP pixels)
       bm[i] += BKP;
       box[i] += p.step_x;
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
-template <int BMW, int BNW, int BKP, bool ONES = false>
+template <int BMW, int BNW, int BKP, bool ONES = false, int NW = 4>
 static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t stream) {
   size_t lds = MAX_TAPS * 4 + (BKP == 32 ? 3 : 2) * (size_t)BKP * (BMW * 2 + BNW * 2);
   unsigned mt = (a.Cout + BMW - 1) / BMW, nt = (a.K + BNW - 1) / BNW;
@@ -359,11 +364,11 @@ static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t stream) {
   (void)hipGetDevice(&dev);
   dev = (dev >= 0 && dev < 64) ? dev : 0;
   if (!attr_set[dev] && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, BKP, ONES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, BKP, ONES, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set[dev] = true;
   }
   unsigned split_groups = (splits + 7) / 8;
-  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, BKP, ONES>), dim3(mt * nt * split_groups * 8), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, BKP, ONES, NW>), dim3(mt * nt * split_groups * 8), dim3(64 * NW), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -393,6 +398,8 @@ extern "C" int dtfa_conv_wgrad(WgradArgs* a, int bmw, int bnw, int bkp, int spli
   }
 #define CASE(A_, B_, C_) \
   if (bmw == A_ && bnw == B_ && bkp == C_) return launch_wgrad<A_, B_, C_>(*a, splits, stream);
+  if (bmw == 256 && bnw == 256 && bkp == 32) return launch_wgrad<256, 256, 32, false, 8>(*a, splits, stream);
+  if (bmw == 256 && bnw == 256 && bkp == 64) return launch_wgrad<256, 256, 64, false, 8>(*a, splits, stream);
   CASE(256, 128, 32)
   CASE(128, 256, 32)
   CASE(64, 256, 32)

@@ -130,11 +130,13 @@ def save(path: Optional[str] = None, merge: bool = True) -> str:
         try:
             with open(path) as f:
                 old = json.load(f)
-            for kind in out:
+            for kind in list(out):
                 out[kind].update(old.get(kind, {}))
+            for k, v in old.items():   # notes kept beside the tables ("_about")
+                out.setdefault(k, v)
         except (OSError, ValueError):
             pass
-    for kind in out:
+    for kind in ("igemm", "wgrad"):
         for k, v in _db[kind].items():
             if k not in out[kind]:
                 out[kind][k] = {"best": v}

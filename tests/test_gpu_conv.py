@@ -144,6 +144,27 @@ def test_conv_large_tiles():
     assert (dw.cpu() - wr.grad).abs().max().item() <= 2e-2 * wr.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("tile", ["256,256,32,5", "256,256,64,3", "256,256,32,1"])
+@pytest.mark.parametrize("case", [(6, 14, 14, 256, 256, 3, 3, 1, 1, "SAME"), (5, 7, 9, 264, 520, 1, 1, 1, 1, "VALID"),
+                                  (4, 15, 15, 256, 256, 3, 3, 2, 2, "SAME")])
+def test_wgrad_on_the_eight_wave_tile(case, tile, monkeypatch):
+    """The 256 x 256 weight-gradient tile (512 threads, 2 x 4 waves) against fp32 autograd: whole tiles, tiles with
+    padding rows and columns (264 -> 520 channels), a strided layer; several splits and one."""
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case, 11)
+    xr = x.bfloat16().float().requires_grad_(True)
+    wr = w.bfloat16().float().requires_grad_(True)
+    y = ref.conv2d(xr, wr, (sy, sx), pads)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(12)).bfloat16()
+    y.backward(dy.float())
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    monkeypatch.setenv("DTFA_WGRAD_TILE", tile)
+    assert cv.pick_wgrad_tile(B * plan.oh * plan.ow, Cout, plan.K, Cin) == tuple(int(t) for t in tile.split(","))
+    dw = cv.conv_wgrad(xr.detach().bfloat16().cuda(), dy.cuda(), plan)
+    torch.cuda.synchronize()
+    assert (dw.cpu() - wr.grad).abs().max().item() <= 2e-2 * wr.grad.abs().max().item()
+
+
 @pytest.mark.parametrize("case", [(10, 16, 128, 1024, 1024, 1, 1, 1, 1, "VALID"), (12, 102, 128, 32, 128, 3, 3, 1, 1, "SAME")])
 def test_tail_of_last_round_recut_into_small_tiles(case, monkeypatch):
     """A layer whose macro tiles fill whole rounds of the chip plus a fraction of one is covered by two launches

@@ -25,10 +25,19 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "distributed_tensorflow_amd", "ops", "tuned_gfx950.json"))
     ap.add_argument("--configs", default="resnet50:2048,flower_cnn:1024,inception_v3_head:256,inception_v3_finetune:512")
     ap.add_argument("--fresh", action="store_true")
+    ap.add_argument("--drop", default="", help="kinds of entries (igemm, wgrad) to measure again: removed from --out first")
     a = ap.parse_args()
     os.environ["DTFA_TUNE_DB"] = a.out
     if a.fresh and os.path.exists(a.out):
         os.remove(a.out)
+    if a.drop and os.path.exists(a.out):
+        import json
+        with open(a.out) as f:
+            table = json.load(f)
+        for kind in a.drop.split(","):
+            table[kind] = {}
+        with open(a.out, "w") as f:
+            json.dump(table, f, indent=0, sort_keys=True)
     import bench  # noqa: E402  (after the environment is set: ops.tune reads it at import)
     from distributed_tensorflow_amd.ops import tune
 
@@ -36,8 +45,8 @@ def main():
     torch.cuda.set_device(0)
     for cfg in a.configs.split(","):
         model, batch = cfg.split(":")
-        args = argparse.Namespace(mode="sync_dp", trunk_bn="batch", bucket_mb=32.0, staleness=1, p2p_kb=0, grad_dtype="fp32",
-                                  hip_graph=0, warmup=2, steps=1, image_size=0)
+        # bench.py's own defaults (whatever options it has grown), eager steps
+        args = bench.parse_args(["--hip_graph", "0", "--warmup", "2", "--steps", "1", "--also", "", "--also_modes", ""])
         t0 = time.time()
         before = tune.stats()
         r = bench.run_config(args, model, int(batch), device, 0, 1)
