@@ -398,8 +398,10 @@ def test_launch_geometry_rules():
         slots = 256.0 * per_cu
         rounds = tiles * splits / slots
         whole = -(-tiles * splits // int(slots))
-        # as many splits as fit into a whole number of rounds: one more split would start another round
-        assert 1 <= whole <= 4 and 0 <= whole - rounds < tiles / slots, (cout, bmw, bnw, splits, rounds)
+        # as many splits as fit into a whole number of rounds, in whole splits per XCD (the kernel deals them over the 8
+        # XCDs round-robin): eight more splits would start another round
+        assert splits < 16 or splits % 8 == 0, splits
+        assert 1 <= whole <= 4 and 0 <= whole - rounds < 8 * tiles / slots, (cout, bmw, bnw, splits, rounds)
 
 
 def test_automatic_bucket_size_cuts_small_models_in_several_buckets():
