@@ -396,16 +396,16 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
             cfg = found if len(found) > 5 else tuple(found) + (pick_ksplit(found, M, cout, K),)
     if (_P3 and near_taps and cin == 64 and cout <= 64 and x2 is None and dense_out and iw <= P3_MAX_WIDTH
             and stat_acc is None and bn_tap is None and M >= _P3_MIN_ROWS and not _env_tile("DTFA_CONV_TILE")):
-        cfg = (128, 64, 64, 3, 0, -1)   # conv_p3_kernel: one workgroup per CU, weights and pixel patches in LDS
+        cfg = (128, 64, 64, 3, 0, -1)   # conv_p3_kernel: persistent workgroups, weights in registers, pixel patches in LDS
     return launch(cfg)
 
 
 # Reduction split inside the workgroup (conv_igemm.hip, KSP): for launches of few tiles -- the small-launch path's
 # 64 x 64 x 64 tile -- with a deep reduction, 2 or 4 wave groups each take a slice of every k-tile.
-# conv_p3_kernel (csrc/hip/conv_p3.hip: same-size 3x3 over 64 channels by one persistent workgroup per CU, the
-# weights resident in LDS, the pixels a tile touches over all nine taps staged once): same reduction order as the
-# ordinary kernel, so the same bits.  Two pixel patches of 128 + 2 (width + 1) rows must fit in half a CU's LDS.  Not
-# for the data gradient with batch-norm sums (its epilogue needs the registers the resident weights hold).
+# conv_p3_kernel (csrc/hip/conv_p3.hip: same-size 3x3 over 64 channels by two persistent workgroups per CU, the
+# weights resident in registers, the pixels a tile touches over all nine taps staged once in LDS): same reduction order
+# as the ordinary kernel, so the same bits.  Two pixel patches of 128 + 2 (width + 1) rows must fit in half a CU's LDS.
+# Not for the data gradient with batch-norm sums (its epilogue needs the registers the resident weights hold).
 _P3 = os.environ.get("DTFA_CONV_P3", "1") == "1"
 _P3_MIN_ROWS = int(os.environ.get("DTFA_CONV_P3_MIN_ROWS", str(1 << 16)))
 P3_MAX_WIDTH = 87
