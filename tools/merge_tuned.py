@@ -29,20 +29,27 @@ def main():
             if "rule" not in m or not isinstance(m.get("us"), dict):
                 continue   # carried over, not measured in that run
             us = m["us"]
-            name = lambda c: ",".join(map(str, c))
+
+            def t_of(cfg):
+                """Time of ``cfg`` in this run (entries written before the reduction split existed lack its element)."""
+                for k in (",".join(map(str, cfg)), ",".join(map(str, cfg)) + ",1"):
+                    if k in us:
+                        return us[k]
+                return None
+
             best, rule = m["best"], m["rule"]
             old = table[kind].get(key)
-            keep = old["best"] if old is not None and name(old["best"]) in us else rule
-            if name(keep) not in us:
+            keep = old["best"] if old is not None and t_of(old["best"]) is not None else rule
+            if t_of(keep) is None:
                 keep = best
-            if us[name(best)] < (1.0 - a.margin) * us[name(keep)]:
+            if t_of(best) < (1.0 - a.margin) * t_of(keep):
                 keep = best
-            entry = {"best": list(keep), "us": [us.get(name(rule), us[name(keep)]), us[name(keep)]]}
+            entry = {"best": list(keep), "us": [t_of(rule) if t_of(rule) is not None else t_of(keep), t_of(keep)]}
             if old is None:
                 added += 1
             elif list(old["best"]) != list(keep):
                 changed += 1
-                print("%s %s: %s -> %s (%.1f -> %.1f us)" % (kind, key, old["best"], keep, us[name(old["best"])], us[name(keep)]))
+                print("%s %s: %s -> %s (%.1f -> %.1f us)" % (kind, key, old["best"], keep, t_of(old["best"]), t_of(keep)))
             table[kind][key] = entry
     with open(a.table, "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)
