@@ -44,6 +44,9 @@ def main():
                 keep = best
             if t_of(best) < (1.0 - a.margin) * t_of(keep):
                 keep = best
+            keep = list(keep)
+            if kind == "igemm" and len(keep) == 6 and keep[5] == 1 and tuple(keep[:4]) != (64, 64, 64, 2):
+                keep = keep[:5]   # no reduction split, on a tile that has none: the table's five-element form
             entry = {"best": list(keep), "us": [t_of(rule) if t_of(rule) is not None else t_of(keep), t_of(keep)]}
             if old is None:
                 added += 1
