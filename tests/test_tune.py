@@ -95,3 +95,39 @@ def test_shipped_table_is_well_formed(monkeypatch):
         assert len(k.split(",")) == 7
         bmw, bnw, bkp, splits = v["best"]
         assert (bmw, bnw, bkp) in cv._WGRAD_RESIDENT and 1 <= splits <= 4096, (k, v)
+
+
+def test_merging_a_new_measurement_into_the_shipped_table(tmp_path):
+    """tools/merge_tuned.py: an entry changes only when the new run's winner beats the shipped choice, timed in that same
+    run, by more than the margin; notes beside the tables survive; entries without a reduction split keep five elements."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    table = tmp_path / "table.json"
+    table.write_text(json.dumps({
+        "_about": "note",
+        "igemm": {"1,2,3,4,5,6,7,0": {"best": [128, 128, 32, 3, 1], "us": [10.0, 10.0]}},
+        "wgrad": {"a": {"best": [256, 128, 32, 56], "us": [100.0, 100.0]},
+                  "b": {"best": [128, 128, 32, 64], "us": [50.0, 50.0]}}}))
+    measured = tmp_path / "new.json"
+    measured.write_text(json.dumps({
+        "igemm": {"1,2,3,4,5,6,7,0": {"best": [128, 128, 32, 3, 1, 1], "rule": [128, 128, 32, 3, 1, 1],
+                                      "us": {"128,128,32,3,1,1": 9.0, "128,64,32,3,0": 9.5}}},
+        "wgrad": {"a": {"best": [256, 256, 64, 56], "rule": [256, 128, 32, 56],     # 10 % faster: replaces
+                        "us": {"256,128,32,56": 100.0, "256,256,64,56": 90.0}},
+                  "b": {"best": [128, 128, 64, 64], "rule": [128, 128, 32, 64],     # 1 % faster: within the margin
+                        "us": {"128,128,32,64": 50.0, "128,128,64,64": 49.5}},
+                  "c": {"best": [64, 64, 32, 8], "rule": [64, 64, 32, 16],           # a new key
+                        "us": {"64,64,32,16": 20.0, "64,64,32,8": 12.0}},
+                  "d": {"best": [64, 64, 32, 8]}}}))                                  # carried over, not measured
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "merge_tuned.py"), str(measured), "--table", str(table)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(table.read_text())
+    assert out["_about"] == "note"
+    assert out["wgrad"]["a"] == {"best": [256, 256, 64, 56], "us": [100.0, 90.0]}
+    assert out["wgrad"]["b"]["best"] == [128, 128, 32, 64]
+    assert out["wgrad"]["c"] == {"best": [64, 64, 32, 8], "us": [20.0, 12.0]}
+    assert "d" not in out["wgrad"]
+    assert out["igemm"]["1,2,3,4,5,6,7,0"]["best"] == [128, 128, 32, 3, 1]
