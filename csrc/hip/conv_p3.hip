@@ -22,6 +22,9 @@
 //     LDS) is conv_epilogue of the ordinary kernel, staged in the patch buffer the tile has just finished with; its
 //     stores drain while the next tile is multiplied, and it runs beside the other workgroup's multiplications.
 // 4 waves per workgroup (2 x 2, each 64 x 32 of the 128 x 64 tile), two waves per SIMD with 256 registers each.
+// Images too wide for two workgroups with two patch buffers each (beyond 87 pixels) run with ONE buffer per workgroup:
+// a tile's patch is requested when the previous tile's epilogue has left the buffer and waited for, and what hides the
+// round trip is the CU's other workgroup (two buffers at one workgroup per CU measured slower than the ordinary kernel).
 #include "common.h"
 
 #include "conv_epilogue.h"
@@ -52,7 +55,7 @@ __device__ __forceinline__ void glds16_sbase(const void* base, unsigned lane_off
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_rows, int tiles_per_wg) {
+__global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_rows, int tiles_per_wg, int nbuf) {
   constexpr int BM = P3_BM, BN = P3_BN, ROWB = P3_ROWB, WM = 64, WN = 32, MT = 2, NT = 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* zrow = smem + MAX_TAPS * 4;          // 128 bytes of zeros
@@ -167,7 +170,16 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    if (tile + 1 < tile_end) request_patch(tile + 1, cur ^ 1);
+    if (nbuf == 2) {
+      if (tile + 1 < tile_end) request_patch(tile + 1, cur ^ 1);
+    } else if (tile != tile_begin) {
+      // One buffer (images too wide for two patches per workgroup at two workgroups per CU): this tile's patch is
+      // requested only now that the previous tile's epilogue has left the buffer, and waited for; what hides the round
+      // trip is the CU's other workgroup.
+      request_patch(tile, 0);
+      wait_vmcnt<0>();
+      __syncthreads();
+    }
     const int brow = prow0 + cur * patch_rows;
     char* patch = smem + brow * ROWB;
 
@@ -257,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
     conv_epilogue<BM, BN, EPI, false>(p, acc, patch, wid, lane, m0, 0, tile, true, nullptr);
 #endif
     P3_CLK(4, "epilogue")
-    cur ^= 1;
+    if (nbuf == 2) cur ^= 1;
   }
 #if (P3_DBG & 8)
   if (lane == 0)
@@ -269,8 +281,10 @@ template <int EPI>
 int launch_p3(const ConvArgs& a, hipStream_t stream) {
   int patch_rows = (P3_BM + 2 * (a.IW + 1) + 15) & ~15;   // (a multiple of 16: see request_patch)
   if (patch_rows * P3_ROWB < P3_EP) patch_rows = ((P3_EP + P3_ROWB - 1) / P3_ROWB + 15) & ~15;
-  const size_t lds = P3_HEAD + 2 * (size_t)patch_rows * P3_ROWB;
-  if (lds > 160 * 1024) return -10;
+  // two patch buffers where two workgroups with two each fit into a CU's LDS, else one buffer per workgroup
+  const int nbuf = P3_HEAD + 2 * (size_t)patch_rows * P3_ROWB <= 80 * 1024 ? 2 : 1;
+  const size_t lds = P3_HEAD + nbuf * (size_t)patch_rows * P3_ROWB;
+  if (lds > 80 * 1024) return -10;
   static bool attr_set[64] = {};
   static int cus[64] = {};
   int dev = 0;
@@ -286,12 +300,12 @@ int launch_p3(const ConvArgs& a, hipStream_t stream) {
     cus[dev] = n;
   }
   const unsigned mtiles = (a.M + P3_BM - 1) / P3_BM;
-  // as many workgroups as fit on the chip at once (two per CU where two patches pairs fit in a CU's LDS), each a
+  // as many workgroups as fit on the chip at once (two per CU), each a
   // contiguous range of row tiles (neighbouring tiles share patch rows through L2)
-  const unsigned slots = cus[dev] * (lds <= 80 * 1024 ? 2u : 1u);
+  const unsigned slots = cus[dev] * 2u;
   const unsigned per = (mtiles + slots - 1) / slots;
   const unsigned wgs = (mtiles + per - 1) / per;
-  hipLaunchKernelGGL((conv_p3_kernel<EPI>), dim3(wgs), dim3(256), lds, stream, a, patch_rows, (int)per);
+  hipLaunchKernelGGL((conv_p3_kernel<EPI>), dim3(wgs), dim3(256), lds, stream, a, patch_rows, (int)per, nbuf);
   return (int)hipGetLastError();
 }
 

@@ -404,11 +404,14 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
 # 64 x 64 x 64 tile -- with a deep reduction, 2 or 4 wave groups each take a slice of every k-tile.
 # conv_p3_kernel (csrc/hip/conv_p3.hip: same-size 3x3 over 64 channels by two persistent workgroups per CU, the
 # weights resident in registers, the pixels a tile touches over all nine taps staged once in LDS): same reduction order
-# as the ordinary kernel, so the same bits.  Two pixel patches of 128 + 2 (width + 1) rows must fit in half a CU's LDS.
+# as the ordinary kernel, so the same bits.  Two pixel patches of 128 + 2 (width + 1) rows fit in half a CU's LDS up to 87
+# pixels of width; wider images (to 240) get one patch buffer per workgroup, still two workgroups per CU (112x112
+# 64 -> 32, the flower CNN's second data gradient at batch 1024: 1521 -> 1093 us; with two buffers and ONE workgroup per
+# CU 1776).
 # Not for the data gradient with batch-norm sums (its epilogue needs the registers the resident weights hold).
 _P3 = os.environ.get("DTFA_CONV_P3", "1") == "1"
 _P3_MIN_ROWS = int(os.environ.get("DTFA_CONV_P3_MIN_ROWS", str(1 << 16)))
-P3_MAX_WIDTH = 87
+P3_MAX_WIDTH = int(os.environ.get("DTFA_CONV_P3_MAX_WIDTH", "240"))
 _P3_DGRAD = os.environ.get("DTFA_CONV_P3_DGRAD", "1") == "1"
 _KSPLIT = os.environ.get("DTFA_CONV_KSPLIT", "auto")
 _KSPLIT_MAX_TILES = int(os.environ.get("DTFA_CONV_KSPLIT_MAX_TILES", "512"))

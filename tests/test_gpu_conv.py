@@ -267,14 +267,15 @@ def test_reduction_split_inside_the_workgroup(case, ksp, monkeypatch):
 
 
 @pytest.mark.parametrize("case", [(2, 56, 56, 64, 64), (3, 20, 12, 64, 32), (1, 9, 87, 64, 48), (2, 7, 5, 64, 64),
-                                  (70, 56, 56, 64, 64)])
+                                  (70, 56, 56, 64, 64), (2, 9, 112, 64, 32), (1, 6, 240, 64, 64), (40, 30, 112, 64, 32)])
 def test_same_size_3x3_by_the_persistent_kernel(case, monkeypatch):
     """conv_p3_kernel (3x3, stride 1, 64 input channels: one workgroup per CU walks a range of row tiles with the
     weights resident in LDS; the pixels a tile touches over all nine taps are brought into LDS once, one tile ahead,
     taps read at row offsets, out-of-image taps from a zero row) gives the bits of the ordinary kernel -- the
     reduction order is the same -- for the forward with statistics, the folded scale / bias / ReLU epilogue and the
     data gradient with an addend.  The last case has more tiles than the chip has CUs, so
-    workgroups walk several tiles and both patch buffers are reused."""
+    workgroups walk several tiles and both patch buffers are reused.  Images wider than 87 pixels run with one patch
+    buffer per workgroup (the last case: several tiles per workgroup in that mode)."""
     B, H, W, Cin, Cout = case
     full = (B, H, W, Cin, Cout, 3, 3, 1, 1, "SAME")
     x, w, pads = _mk(full, 31)
@@ -310,6 +311,7 @@ def test_same_size_3x3_by_the_persistent_kernel(case, monkeypatch):
     monkeypatch.setattr(cv, "_P3", False)
     want = run()
     monkeypatch.setattr(cv, "_P3", True)
+    assert cv.p3_takes(plan, B, Cin, Cout) and cv.p3_takes(dplan, B, 64, Cout)   # ... or the comparison would be idle
     got = run()
     assert cv.pick_fwd_tile(B * H * W, Cout, 576, True)[0] in (64, 128)
     for a, b in zip(got, want):
