@@ -22,6 +22,8 @@
 //     LDS) is conv_epilogue of the ordinary kernel, staged in the patch buffer the tile has just finished with; its
 //     stores drain while the next tile is multiplied, and it runs beside the other workgroup's multiplications.
 // 4 waves per workgroup (2 x 2, each 64 x 32 of the 128 x 64 tile), two waves per SIMD with 256 registers each.
+// Layers with more than 64 output channels (up to 256) run as slices of 64 columns, one workgroup each over the same
+// rows; neighbours in the grid, so the second slice finds the patch rows in L2.
 // Images too wide for two workgroups with two patch buffers each (beyond 87 pixels) run with ONE buffer per workgroup:
 // a tile's patch is requested when the previous tile's epilogue has left the buffer and waited for, and what hides the
 // round trip is the CU's other workgroup (two buffers at one workgroup per CU measured slower than the ordinary kernel).
@@ -55,7 +57,8 @@ __device__ __forceinline__ void glds16_sbase(const void* base, unsigned lane_off
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_rows, int tiles_per_wg, int nbuf) {
+__global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_rows, int tiles_per_wg, int nbuf,
+                                                         int nslices) {
   constexpr int BM = P3_BM, BN = P3_BN, ROWB = P3_ROWB, WM = 64, WN = 32, MT = 2, NT = 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* zrow = smem + MAX_TAPS * 4;          // 128 bytes of zeros
@@ -67,7 +70,11 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;
   const unsigned mtiles = (p.M + BM - 1) / BM;
-  const unsigned tile_begin = blockIdx.x * (unsigned)tiles_per_wg;
+  // More than 64 output channels: slices of 64 columns, each a workgroup of its own over the same range of row tiles
+  // (neighbours in the grid, so that the second finds the patch rows the first brought into L2).
+  const unsigned range = blockIdx.x / (unsigned)nslices;
+  const int n0 = (int)(blockIdx.x % (unsigned)nslices) * BN;
+  const unsigned tile_begin = range * (unsigned)tiles_per_wg;
   unsigned tile_end = tile_begin + (unsigned)tiles_per_wg;
   if (tile_end > mtiles) tile_end = mtiles;
   if (tile_begin >= tile_end) return;
@@ -121,10 +128,10 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
 
   // ---- the wave's weights: B fragments of all taps, [Cout][T * 64] global -> registers, once ----
   const int khalf = lane >> 5;
-  const bool wave_live = wc * WN < p.Cout;
+  const bool wave_live = n0 + wc * WN < p.Cout;
   bf16x8 bw[T][4];
   {
-    const int wn = wc * WN + (lane & 31);
+    const int wn = n0 + wc * WN + (lane & 31);
     const bf16* wrow = p.w + (size_t)(wn < p.Cout ? wn : 0) * p.K + khalf * 8;
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
       if (sum == 123.456f) p.y[0] = (bf16)sum;
     }
 #else
-    conv_epilogue<BM, BN, EPI, false>(p, acc, patch, wid, lane, m0, 0, tile, true, nullptr);
+    conv_epilogue<BM, BN, EPI, false>(p, acc, patch, wid, lane, m0, n0, tile, true, nullptr);
 #endif
     P3_CLK(4, "epilogue")
     if (nbuf == 2) cur ^= 1;
@@ -302,16 +309,18 @@ int launch_p3(const ConvArgs& a, hipStream_t stream) {
   const unsigned mtiles = (a.M + P3_BM - 1) / P3_BM;
   // as many workgroups as fit on the chip at once (two per CU), each a
   // contiguous range of row tiles (neighbouring tiles share patch rows through L2)
-  const unsigned slots = cus[dev] * 2u;
+  const unsigned nslices = (unsigned)(a.Cout + P3_BN - 1) / P3_BN;
+  const unsigned slots = cus[dev] * 2u / nslices;
   const unsigned per = (mtiles + slots - 1) / slots;
   const unsigned wgs = (mtiles + per - 1) / per;
-  hipLaunchKernelGGL((conv_p3_kernel<EPI>), dim3(wgs), dim3(256), lds, stream, a, patch_rows, (int)per, nbuf);
+  hipLaunchKernelGGL((conv_p3_kernel<EPI>), dim3(wgs * nslices), dim3(256), lds, stream, a, patch_rows, (int)per, nbuf,
+                     (int)nslices);
   return (int)hipGetLastError();
 }
 
 // The shapes the kernel takes (the caller vouches that every tap offset lies within one pixel).
 bool p3_ok(const ConvArgs& a) {
-  return a.Cin == 64 && a.Cout <= 64 && a.T == 9 && a.K == 9 * 64 && a.isy == 1 && a.isx == 1 && a.osy == 1 &&
+  return a.Cin == 64 && a.Cout <= 256 && a.T == 9 && a.K == 9 * 64 && a.isy == 1 && a.isx == 1 && a.osy == 1 &&
          a.osx == 1 && a.oy0 == 0 && a.ox0 == 0 && a.dense_out && !a.pointwise && a.x2 == nullptr && a.IH == a.OYn &&
          a.IW == a.OXn && a.IH == a.OH && a.IW == a.OW && a.tile_m_base == 0 && a.tile_m_count == 0 &&
          a.stat_row_base == 0 && a.stat_acc == nullptr && a.M % (a.IH * a.IW) == 0;
