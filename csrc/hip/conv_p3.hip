@@ -1,4 +1,4 @@
-// Persistent same-size 3x3 convolution over 64 input channels for gfx950 (MI355X): weights resident in registers,
+// Persistent same-size 3x3 convolution over 64 (or 32) input channels for gfx950 (MI355X): weights resident in registers,
 // the pixel operand staged in LDS once per tile and double-buffered.
 //
 // The ordinary implicit-GEMM kernel (conv_igemm.hip) serves a 3x3 layer by gathering a 128 x 64 pixel tile once per
@@ -37,7 +37,7 @@
 
 namespace {
 
-constexpr int P3_BM = 128, P3_BN = 64, P3_CIN = 64, P3_ROWB = 128;
+constexpr int P3_BM = 128, P3_BN = 64;
 constexpr int P3_EP = 4 * 64 * (32 * 2 + EP_PAD) + 2 * 32 * 2 * 4;           // epilogue row tiles + statistics exchange
 constexpr int P3_HEAD = MAX_TAPS * 4 + 128;                              // (unused words) + a pixel row of zeros
 
@@ -56,10 +56,19 @@ __device__ __forceinline__ void glds16_sbase(const void* base, unsigned lane_off
       : "memory");
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_rows, int tiles_per_wg, int nbuf,
-                                                         int nslices) {
-  constexpr int BM = P3_BM, BN = P3_BN, ROWB = P3_ROWB, WM = 64, WN = 32, MT = 2, NT = 1;
+// CIN: input channels, 64 or 32 (pixel rows of 128 or 64 bytes; a tap is four or two k-steps of 16).
+// SLICED: more than 64 output channels (a template parameter: as a run-time value the slice offset costs the plain
+// kernel the registers it does not have).
+// NBUF: patch buffers per workgroup, 2 or 1 (see above; a template parameter for the same reason).
+template <int EPI, int CIN, bool SLICED, int NBUF>
+__global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_rows, int tiles_per_wg, int nslices) {
+  constexpr int BM = P3_BM, BN = P3_BN, ROWB = CIN * 2, WM = 64, WN = 32, MT = 2, NT = 1;
+  constexpr int CPR = ROWB / 16;      // 16-byte chunks per pixel row
+  constexpr int RPI = 64 / CPR;       // pixel rows per LDS-DMA wave instruction
+  constexpr int NV = 16 / RPI;        // distinct source permutations of an instruction (the swizzle repeats every 16 rows)
+  constexpr int KS = CIN / 16;        // k-steps per tap
+  constexpr int HS = KS / 2;          // steps of two k-steps per tap
+  static_assert(CIN == 64 || CIN == 32, "pixel rows of 128 or 64 bytes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* zrow = smem + MAX_TAPS * 4;          // 128 bytes of zeros
   char* patch0 = smem + P3_HEAD;
@@ -72,49 +81,49 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
   const unsigned mtiles = (p.M + BM - 1) / BM;
   // More than 64 output channels: slices of 64 columns, each a workgroup of its own over the same range of row tiles
   // (neighbours in the grid, so that the second finds the patch rows the first brought into L2).
-  const unsigned range = blockIdx.x / (unsigned)nslices;
-  const int n0 = (int)(blockIdx.x % (unsigned)nslices) * BN;
+  const unsigned range = SLICED ? blockIdx.x / (unsigned)nslices : blockIdx.x;
+  const int n0 = SLICED ? (int)(blockIdx.x % (unsigned)nslices) * BN : 0;
   const unsigned tile_begin = range * (unsigned)tiles_per_wg;
   unsigned tile_end = tile_begin + (unsigned)tiles_per_wg;
   if (tile_end > mtiles) tile_end = mtiles;
   if (tile_begin >= tile_end) return;
   const int margin = p.IW + 1;
   constexpr int T = 9;
-  constexpr int ZROW = MAX_TAPS * 4 / ROWB;   // LDS row (128-byte units) of the zero row
+  constexpr int ZROW = MAX_TAPS * 4 / ROWB;   // LDS row (units of a pixel row) of the zero row
 
   if (tid < 32) ((float*)zrow)[tid] = 0.f;
 
-  // Rows of LDS are addressed in 128-byte units from the start of the workgroup's allocation; the 16-byte chunks of
+  // Rows of LDS are addressed in units of a pixel row from the start of the workgroup's allocation; the 16-byte chunks of
   // a row are stored permuted by swz_of_row of that absolute row index, so that 16 lanes reading the same logical
   // chunk of 16 consecutive rows touch every bank once.
   const int prow0 = P3_HEAD / ROWB;           // first row of patch buffer 0
 
-  // ---- the patch of a tile: 8 pixel rows per wave instruction, dealt over the waves ----
+  // ---- the patch of a tile: 8 (16) pixel rows per wave instruction, dealt over the waves ----
   // patch_rows is a multiple of 16 and so is the swizzle's period: a lane's source chunk for instruction j depends
-  // on the parity of j only, not on the buffer.  Source = uniform 64-bit base (first pixel row of the instruction)
-  // + a per-lane 32-bit offset, one of two.
-  const int row_in_inst = lane >> 3;
-  unsigned lane_off[2];
+  // on j modulo NV only, not on the buffer.  Source = uniform 64-bit base (first pixel row of the instruction)
+  // + a per-lane 32-bit offset, one of NV.
+  const int row_in_inst = lane / CPR;
+  unsigned lane_off[NV];
 #pragma unroll
-  for (int par = 0; par < 2; ++par)
-    lane_off[par] = row_in_inst * ROWB + (((lane & 7) ^ swz_of_row<64>(prow0 + par * 8 + row_in_inst)) << 4);
-  const int ninst = patch_rows >> 3;
+  for (int par = 0; par < NV; ++par)
+    lane_off[par] = row_in_inst * ROWB + (((lane % CPR) ^ swz_of_row<CIN>(prow0 + par * RPI + row_in_inst)) << 4);
+  const int ninst = patch_rows / RPI;
   auto request_patch = [&](unsigned tile, int buf) {
     const int brow = prow0 + buf * patch_rows;
     const long long gp0 = (long long)tile * BM - margin;
     for (int j = wid; j < ((P3_DBG & 4) ? 0 : ninst); j += 4) {
-      const long long first = gp0 + j * 8;    // uniform
-      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((brow + j * 8) * ROWB);
-      if (first >= 0 && first + 8 <= (long long)p.M) {
-        glds16_sbase(p.x + first * 64, lane_off[j & 1], dst);
+      const long long first = gp0 + j * RPI;    // uniform
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((brow + j * RPI) * ROWB);
+      if (first >= 0 && first + RPI <= (long long)p.M) {
+        glds16_sbase(p.x + first * CIN, lane_off[j & (NV - 1)], dst);
       } else {   // the tensor's first and last rows: out-of-range rows read zeros (their taps are masked anyway)
         const long long gp = first + row_in_inst;
-        const bf16* src = (gp >= 0 && gp < (long long)p.M) ? (const bf16*)((const char*)(p.x + first * 64) + lane_off[j & 1]) : p.zero;
+        const bf16* src = (gp >= 0 && gp < (long long)p.M) ? (const bf16*)((const char*)(p.x + first * CIN) + lane_off[j & (NV - 1)]) : p.zero;
         glds16_untracked(src, smem + dst);
       }
     }
   };
-  request_patch(tile_begin, 0);
+  if (NBUF == 2) request_patch(tile_begin, 0);   // (one buffer: every tile's patch is requested inside the loop)
 
   // ---- the taps, in scalar registers: row offset inside a patch and index into a lane's 3 x 3 validity mask ----
   int toff[T], tbit[T];
@@ -126,19 +135,19 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
     tbit[t] = __builtin_amdgcn_readfirstlane((dy + 1) * 3 + dx + 1);
   }
 
-  // ---- the wave's weights: B fragments of all taps, [Cout][T * 64] global -> registers, once ----
+  // ---- the wave's weights: B fragments of all taps, [Cout][T * CIN] global -> registers, once ----
   const int khalf = lane >> 5;
   const bool wave_live = n0 + wc * WN < p.Cout;
-  bf16x8 bw[T][4];
+  bf16x8 bw[T][KS];
   {
     const int wn = n0 + wc * WN + (lane & 31);
     const bf16* wrow = p.w + (size_t)(wn < p.Cout ? wn : 0) * p.K + khalf * 8;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (wn < p.Cout) v = *(const bf16x8*)(wrow + t * P3_CIN + ks * 16);
+        if (wn < p.Cout) v = *(const bf16x8*)(wrow + t * CIN + ks * 16);
         bw[t][ks] = v;
       }
   }
@@ -177,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    if (nbuf == 2) {
+    if (NBUF == 2) {
       if (tile + 1 < tile_end) request_patch(tile + 1, cur ^ 1);
-    } else if (tile != tile_begin) {
+    } else {
       // One buffer (images too wide for two patches per workgroup at two workgroups per CU): this tile's patch is
       // requested only now that the previous tile's epilogue has left the buffer, and waited for; what hides the round
       // trip is the CU's other workgroup.
@@ -214,13 +223,13 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
       bf16x8 af[2][2][MT];
       unsigned abase[MT];   // LDS byte address of the lane's chunk for k-slice 0 of the tap being read
       auto read_step = [&](int s, int dst) {
-        const int t = s >> 1, h = s & 1;
+        const int t = s / HS, h = s % HS;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           if (h == 0) {
             const bool ok = ((okmask[mt] >> tbit[t]) & 1u) != 0;
             const unsigned R = ok ? (unsigned)(brow + rloc[mt] + toff[t]) : (unsigned)ZROW;
-            abase[mt] = (R << 7) | ((((R >> 1) & 7u) ^ (unsigned)khalf) << 4);
+            abase[mt] = R * (unsigned)ROWB + (((unsigned)swz_of_row<CIN>((int)R) ^ (unsigned)khalf) << 4);
           }
 #pragma unroll
           for (int k2 = 0; k2 < 2; ++k2)
@@ -229,8 +238,8 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
       };
       read_step(0, 0);
 #pragma unroll
-      for (int s = 0; s < 2 * T; ++s) {
-        if (s + 1 < 2 * T) read_step(s + 1, (s + 1) & 1);
+      for (int s = 0; s < HS * T; ++s) {
+        if (s + 1 < HS * T) read_step(s + 1, (s + 1) & 1);
         // (keeps the scheduler from sinking the reads behind the multiplications they are meant to run beside)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                af[s & 1][k2][mt], bw[s >> 1][(s & 1) * 2 + k2],
+                af[s & 1][k2][mt], bw[s / HS][(s % HS) * 2 + k2],
                 (s == 0 && k2 == 0) ? f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[mt][0], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
     conv_epilogue<BM, BN, EPI, false>(p, acc, patch, wid, lane, m0, n0, tile, true, nullptr);
 #endif
     P3_CLK(4, "epilogue")
-    if (nbuf == 2) cur ^= 1;
+    if (NBUF == 2) cur ^= 1;
   }
 #if (P3_DBG & 8)
   if (lane == 0)
@@ -284,21 +293,17 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
 #endif
 }
 
-template <int EPI>
-int launch_p3(const ConvArgs& a, hipStream_t stream) {
-  int patch_rows = (P3_BM + 2 * (a.IW + 1) + 15) & ~15;   // (a multiple of 16: see request_patch)
-  if (patch_rows * P3_ROWB < P3_EP) patch_rows = ((P3_EP + P3_ROWB - 1) / P3_ROWB + 15) & ~15;
-  // two patch buffers where two workgroups with two each fit into a CU's LDS, else one buffer per workgroup
-  const int nbuf = P3_HEAD + 2 * (size_t)patch_rows * P3_ROWB <= 80 * 1024 ? 2 : 1;
-  const size_t lds = P3_HEAD + nbuf * (size_t)patch_rows * P3_ROWB;
-  if (lds > 80 * 1024) return -10;
+template <int EPI, int CIN, bool SLICED, int NBUF>
+int launch_p3(const ConvArgs& a, int patch_rows, hipStream_t stream) {
+  constexpr int ROWB = CIN * 2;
+  const size_t lds = P3_HEAD + NBUF * (size_t)patch_rows * ROWB;
   static bool attr_set[64] = {};
   static int cus[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev = (dev >= 0 && dev < 64) ? dev : 0;
   if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute((const void*)conv_p3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_p3_kernel<EPI, CIN, SLICED, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = true;
   }
   if (cus[dev] == 0) {
@@ -313,14 +318,14 @@ int launch_p3(const ConvArgs& a, hipStream_t stream) {
   const unsigned slots = cus[dev] * 2u / nslices;
   const unsigned per = (mtiles + slots - 1) / slots;
   const unsigned wgs = (mtiles + per - 1) / per;
-  hipLaunchKernelGGL((conv_p3_kernel<EPI>), dim3(wgs * nslices), dim3(256), lds, stream, a, patch_rows, (int)per, nbuf,
-                     (int)nslices);
+  hipLaunchKernelGGL((conv_p3_kernel<EPI, CIN, SLICED, NBUF>), dim3(wgs * nslices), dim3(256), lds, stream, a, patch_rows,
+                     (int)per, (int)nslices);
   return (int)hipGetLastError();
 }
 
 // The shapes the kernel takes (the caller vouches that every tap offset lies within one pixel).
 bool p3_ok(const ConvArgs& a) {
-  return a.Cin == 64 && a.Cout <= 256 && a.T == 9 && a.K == 9 * 64 && a.isy == 1 && a.isx == 1 && a.osy == 1 &&
+  return (a.Cin == 64 || a.Cin == 32) && a.Cout <= 256 && a.T == 9 && a.K == 9 * a.Cin && a.isy == 1 && a.isx == 1 && a.osy == 1 &&
          a.osx == 1 && a.oy0 == 0 && a.ox0 == 0 && a.dense_out && !a.pointwise && a.x2 == nullptr && a.IH == a.OYn &&
          a.IW == a.OXn && a.IH == a.OH && a.IW == a.OW && a.tile_m_base == 0 && a.tile_m_count == 0 &&
          a.stat_row_base == 0 && a.stat_acc == nullptr && a.M % (a.IH * a.IW) == 0;
@@ -334,7 +339,21 @@ int conv_p3_launch(const ConvArgs& a, hipStream_t stream) {
   // a second tensor, and with the weights holding 144 registers there are neither registers to keep enough of those
   // loads in flight nor a second workgroup's worth of waves to hide them (measured: 1.33 ms against 1.18 ms).
   if (a.bn_y != nullptr || a.bn_gate_store) return -10;
-  if (a.stats != nullptr) return launch_p3<1>(a, stream);
-  if (a.bias != nullptr || a.relu || a.oscale != nullptr || a.ldo != a.Cout) return launch_p3<2>(a, stream);
-  return launch_p3<0>(a, stream);
+  const int epi = a.stats != nullptr ? 1 : (a.bias != nullptr || a.relu || a.oscale != nullptr || a.ldo != a.Cout) ? 2 : 0;
+  const bool sliced = a.Cout > P3_BN;
+  const int rowb = a.Cin * 2;
+  int patch_rows = (P3_BM + 2 * (a.IW + 1) + 15) & ~15;   // (a multiple of 16: see request_patch)
+  if (patch_rows * rowb < P3_EP) patch_rows = ((P3_EP + rowb - 1) / rowb + 15) & ~15;
+  // two patch buffers where two workgroups with two each fit into a CU's LDS, else one buffer per workgroup
+  const int nbuf = P3_HEAD + 2 * (size_t)patch_rows * rowb <= 80 * 1024 ? 2 : 1;
+  if (P3_HEAD + nbuf * (size_t)patch_rows * rowb > 80 * 1024) return -10;
+#define P3_CASE(E, C, S) \
+  if (epi == E && a.Cin == C && sliced == S) \
+    return nbuf == 2 ? launch_p3<E, C, S, 2>(a, patch_rows, stream) : launch_p3<E, C, S, 1>(a, patch_rows, stream);
+  P3_CASE(0, 64, false) P3_CASE(1, 64, false) P3_CASE(2, 64, false)
+  P3_CASE(0, 64, true) P3_CASE(1, 64, true) P3_CASE(2, 64, true)
+  P3_CASE(0, 32, false) P3_CASE(1, 32, false) P3_CASE(2, 32, false)
+  P3_CASE(0, 32, true) P3_CASE(1, 32, true) P3_CASE(2, 32, true)
+#undef P3_CASE
+  return -10;
 }

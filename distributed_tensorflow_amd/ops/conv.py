@@ -394,7 +394,7 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
             found = tune.measure("igemm", key, _igemm_candidates(M, cout, K), launch, rule)
         if found is not None:   # entries measured before the reduction split existed carry no split: the rule adds it
             cfg = found if len(found) > 5 else tuple(found) + (pick_ksplit(found, M, cout, K),)
-    if (_P3 and near_taps and cin == 64 and cout <= P3_MAX_COUT and x2 is None and dense_out and iw <= P3_MAX_WIDTH
+    if (_P3 and near_taps and cin in P3_CINS and cout <= P3_MAX_COUT and x2 is None and dense_out and iw <= P3_MAX_WIDTH
             and stat_acc is None and bn_tap is None and M >= _P3_MIN_ROWS and not _env_tile("DTFA_CONV_TILE")):
         cfg = (128, 64, 64, 3, 0, -1)   # conv_p3_kernel: persistent workgroups, weights in registers, pixel patches in LDS
     return launch(cfg)
@@ -413,6 +413,7 @@ _P3 = os.environ.get("DTFA_CONV_P3", "1") == "1"
 _P3_MIN_ROWS = int(os.environ.get("DTFA_CONV_P3_MIN_ROWS", str(1 << 16)))
 P3_MAX_WIDTH = int(os.environ.get("DTFA_CONV_P3_MAX_WIDTH", "240"))
 P3_MAX_COUT = int(os.environ.get("DTFA_CONV_P3_MAX_COUT", "128"))   # (slices of 64 columns, one workgroup each)
+P3_CINS = tuple(int(c) for c in os.environ.get("DTFA_CONV_P3_CINS", "32,64").split(",") if c)   # input channels it is built for
 _P3_DGRAD = os.environ.get("DTFA_CONV_P3_DGRAD", "1") == "1"
 _KSPLIT = os.environ.get("DTFA_CONV_KSPLIT", "auto")
 _KSPLIT_MAX_TILES = int(os.environ.get("DTFA_CONV_KSPLIT_MAX_TILES", "512"))
@@ -639,7 +640,7 @@ def dgrad_can_tap(plan: ConvPlan) -> bool:
 def p3_takes(plan: ConvPlan, B: int, cin: int, cout: int) -> bool:
     """The persistent 3x3 kernel serves a same-size convolution ``cin -> cout`` of this plan's geometry over ``B``
     images (the forward of the plan, or its data gradient with the channel counts swapped)."""
-    return (_P3 and plan.near_taps and cin == 64 and cout <= P3_MAX_COUT and plan.iw <= P3_MAX_WIDTH
+    return (_P3 and plan.near_taps and cin in P3_CINS and cout <= P3_MAX_COUT and plan.iw <= P3_MAX_WIDTH
             and B * plan.ih * plan.iw >= _P3_MIN_ROWS and not _env_tile("DTFA_CONV_TILE"))
 
 

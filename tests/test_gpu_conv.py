@@ -176,6 +176,7 @@ def test_tail_of_last_round_recut_into_small_tiles(case, monkeypatch):
     xb, wb = x.bfloat16().cuda(), w.bfloat16().cuda()
     plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
     M = B * plan.oh * plan.ow
+    monkeypatch.setattr(cv, "_P3", False)           # (the second case is a shape the persistent kernel would take)
     monkeypatch.setattr(cv, "_WIDE", True)          # the rules may hand out the 256 x 128 macro tile (second case)
     monkeypatch.setattr(cv.tune, "MODE", "off")     # ... and the rules, not a measured table, choose here
     tile = cv.pick_fwd_tile(M, Cout, plan.K, True)
@@ -268,7 +269,8 @@ def test_reduction_split_inside_the_workgroup(case, ksp, monkeypatch):
 
 @pytest.mark.parametrize("case", [(2, 56, 56, 64, 64), (3, 20, 12, 64, 32), (1, 9, 87, 64, 48), (2, 7, 5, 64, 64),
                                   (70, 56, 56, 64, 64), (2, 9, 112, 64, 32), (1, 6, 240, 64, 64), (40, 30, 112, 64, 32),
-                                  (2, 28, 28, 64, 128), (3, 20, 12, 64, 96)])
+                                  (2, 28, 28, 64, 128), (3, 20, 12, 64, 96),
+                                  (2, 30, 112, 32, 64), (3, 17, 9, 32, 32), (1, 12, 147, 32, 96), (30, 40, 56, 32, 64)])
 def test_same_size_3x3_by_the_persistent_kernel(case, monkeypatch):
     """conv_p3_kernel (3x3, stride 1, 64 input channels: one workgroup per CU walks a range of row tiles with the
     weights resident in LDS; the pixels a tile touches over all nine taps are brought into LDS once, one tile ahead,
@@ -277,7 +279,7 @@ def test_same_size_3x3_by_the_persistent_kernel(case, monkeypatch):
     data gradient with an addend.  The last case has more tiles than the chip has CUs, so
     workgroups walk several tiles and both patch buffers are reused.  Images wider than 87 pixels run with one patch
     buffer per workgroup (several tiles per workgroup in that mode: 40 x 30 x 112); more than 64 output channels are
-    slices of 64 columns, one workgroup each (the last two cases)."""
+    slices of 64 columns, one workgroup each; the last four cases have 32 input channels (pixel rows of 64 bytes)."""
     B, H, W, Cin, Cout = case
     full = (B, H, W, Cin, Cout, 3, 3, 1, 1, "SAME")
     x, w, pads = _mk(full, 31)
@@ -285,9 +287,9 @@ def test_same_size_3x3_by_the_persistent_kernel(case, monkeypatch):
     plan = cv.get_plan(H, W, Cin, Cout, 3, 3, 1, 1, pads, "cuda")
     assert plan.near_taps
     g = torch.Generator().manual_seed(32)
-    dy = torch.randn(B, H, W, 64, generator=g).bfloat16().cuda()
-    wd = (torch.randn(64, 3, 3, Cout, generator=g) * 0.05).bfloat16().cuda()    # a layer Cout -> 64: its dgrad reads 64
-    dplan = cv.get_plan(H, W, Cout, 64, 3, 3, 1, 1, pads, "cuda")
+    dy = torch.randn(B, H, W, Cin, generator=g).bfloat16().cuda()
+    wd = (torch.randn(Cin, 3, 3, Cout, generator=g) * 0.05).bfloat16().cuda()   # a layer Cout -> Cin: its dgrad reads Cin
+    dplan = cv.get_plan(H, W, Cout, Cin, 3, 3, 1, 1, pads, "cuda")
     addend = torch.randn(B, H, W, Cout, generator=g).bfloat16().cuda()
     scale = (torch.rand(Cout, generator=g) + 0.5).cuda()
     shift = torch.randn(Cout, generator=g).cuda()
@@ -314,9 +316,9 @@ def test_same_size_3x3_by_the_persistent_kernel(case, monkeypatch):
     monkeypatch.setattr(cv, "_P3", False)
     want = run()
     monkeypatch.setattr(cv, "_P3", True)
-    assert cv.p3_takes(plan, B, Cin, Cout) and cv.p3_takes(dplan, B, 64, Cout)   # ... or the comparison would be idle
+    assert cv.p3_takes(plan, B, Cin, Cout) and cv.p3_takes(dplan, B, Cin, Cout)   # ... or the comparison would be idle
     got = run()
-    assert cv.pick_fwd_tile(B * H * W, Cout, 576, True)[0] in (64, 128)
+    assert cv.pick_fwd_tile(B * H * W, Cout, 9 * Cin, True)[0] in (64, 128)
     for a, b in zip(got, want):
         if a.dtype == torch.bfloat16:
             assert torch.equal(a, b)
