@@ -813,6 +813,17 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
         hipk.check(L.dtfa_wgrad_reduce(slab.data_ptr(), splits, n, f32, b16, 1 if acc else 0, hipk.stream()),
                    "wgrad_reduce")
 
+    if wgrad_p3_takes(plan, M) and not colsum:
+        # persistent kernel: the whole 64 x 576 gradient in the registers of each resident workgroup, one slab each
+        slabs = L.dtfa_conv_wp3_slabs(M)
+        slab = hipk.workspace(x.device, slabs * n * 4)
+        a.slab = slab.data_ptr()
+        hipk.check(L.dtfa_conv_wp3(C.byref(a), hipk.stream()), "conv_wp3")
+        f32 = out.data_ptr() if out.dtype == torch.float32 else None
+        b16 = out.data_ptr() if out.dtype == torch.bfloat16 else None
+        hipk.check(L.dtfa_wgrad_reduce(slab.data_ptr(), slabs, n, f32, b16, 1 if accumulate else 0, hipk.stream()),
+                   "wgrad_reduce")
+        return out
     rule = pick_wgrad_tile(M, plan.cout, plan.K, plan.cin)
     cfg = rule
     if tune.MODE != "off" and not _env_tile("DTFA_WGRAD_TILE"):
@@ -829,6 +840,17 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
     if colsum:
         return out, both[n:]
     return out
+
+
+# conv_wp3_kernel (csrc/hip/conv_wp3.hip): the weight gradient of a same-size 3x3 layer 64 -> 64 by persistent
+# workgroups that hold the whole gradient in registers and stage every pixel once per tile.
+_WGRAD_P3 = os.environ.get("DTFA_WGRAD_P3", "1") == "1"
+_WGRAD_P3_MIN_ROWS = int(os.environ.get("DTFA_WGRAD_P3_MIN_ROWS", str(1 << 16)))
+
+
+def wgrad_p3_takes(plan: ConvPlan, M: int) -> bool:
+    return (_WGRAD_P3 and plan.near_taps and plan.cin == 64 and plan.cout == 64 and 16 <= plan.iw <= 180
+            and M >= _WGRAD_P3_MIN_ROWS and not _env_tile("DTFA_WGRAD_TILE"))
 
 
 def _wgrad_candidates(M: int, cout: int, K: int):

@@ -144,6 +144,42 @@ def test_conv_large_tiles():
     assert (dw.cpu() - wr.grad).abs().max().item() <= 2e-2 * wr.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("case", [(2, 56, 56), (3, 20, 17), (1, 16, 180), (5, 7, 16), (30, 56, 56)])
+def test_wgrad_of_same_size_3x3_by_the_persistent_kernel(case, monkeypatch):
+    """conv_wp3_kernel (3x3, stride 1, 64 -> 64: every resident workgroup holds the whole 64 x 576 gradient in registers,
+    walks a range of 128-pixel tiles and stages each tile's dY rows and X patch once; taps read X at row offsets through
+    transposing LDS reads, out-of-image taps from a row of zeros) against fp32 autograd and against the ordinary kernel;
+    written into a new tensor, into a bf16 buffer and accumulated into an fp32 one.  The last case has more tiles than
+    resident workgroups."""
+    B, H, W = case
+    full = (B, H, W, 64, 64, 3, 3, 1, 1, "SAME")
+    x, w, pads = _mk(full, 41)
+    xr = x.bfloat16().float().requires_grad_(True)
+    wr = w.bfloat16().float().requires_grad_(True)
+    y = ref.conv2d(xr, wr, (1, 1), pads)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(42)).bfloat16()
+    y.backward(dy.float())
+    plan = cv.get_plan(H, W, 64, 64, 3, 3, 1, 1, pads, "cuda")
+    xb, dyb = xr.detach().bfloat16().cuda(), dy.cuda()
+    monkeypatch.setattr(cv.tune, "MODE", "off")
+    monkeypatch.setattr(cv, "_WGRAD_P3", False)
+    want = cv.conv_wgrad(xb, dyb, plan)
+    monkeypatch.setattr(cv, "_WGRAD_P3", True)
+    monkeypatch.setattr(cv, "_WGRAD_P3_MIN_ROWS", 0)
+    assert cv.wgrad_p3_takes(plan, B * H * W)
+    got = cv.conv_wgrad(xb, dyb, plan)
+    scale = wr.grad.abs().max().item()
+    assert (got.cpu() - wr.grad).abs().max().item() <= 2e-2 * scale
+    assert (got - want).abs().max().item() <= 1e-4 * scale          # both sum bf16 products in fp32, in different orders
+    assert torch.equal(got, cv.conv_wgrad(xb, dyb, plan))            # reproducible
+    acc = torch.ones_like(got)
+    cv.conv_wgrad(xb, dyb, plan, out=acc, accumulate=True)
+    torch.testing.assert_close(acc, got + 1.0, rtol=0, atol=1e-5 * scale + 1e-6)
+    b16 = torch.empty(got.shape, dtype=torch.bfloat16, device="cuda")
+    cv.conv_wgrad(xb, dyb, plan, out=b16)
+    assert torch.equal(b16, got.bfloat16())
+
+
 @pytest.mark.parametrize("tile", ["256,256,32,5", "256,256,64,3", "256,256,32,1"])
 @pytest.mark.parametrize("case", [(6, 14, 14, 256, 256, 3, 3, 1, 1, "SAME"), (5, 7, 9, 264, 520, 1, 1, 1, 1, "VALID"),
                                   (4, 15, 15, 256, 256, 3, 3, 2, 2, "SAME")])
