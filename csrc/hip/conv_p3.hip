@@ -196,7 +196,11 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
       wait_vmcnt<0>();
       __syncthreads();
     }
-    const int brow = prow0 + cur * patch_rows;
+    // (One buffer: the buffer's row is made opaque per tile.  As a constant it lets the compiler hoist the 18 tap
+    // addresses of a lane out of the tile loop, into registers the kernel does not have: 10 .. 13 spilled.)
+    int curb = cur;
+    if (NBUF == 1) asm volatile("" : "+s"(curb));
+    const int brow = prow0 + curb * patch_rows;
     char* patch = smem + brow * ROWB;
 
     // validity of a lane's rows per tap: bit (dy + 1) * 3 + (dx + 1) says that (oy + dy, ox + dx) is inside the image
