@@ -204,10 +204,23 @@ __device__ __forceinline__ void epi_prefetch(const ConvArgs& p, EpiPrefetch<BM, 
 #define EPI_DBG 0
 #endif
 
+// The (bias, scale) pair of a lane's column ``co`` as conv_epilogue loads it (see its ``held`` argument).
+template <int EPI>
+__device__ __forceinline__ void epi_hold_column(const ConvArgs& p, int co, float* pair) {
+  pair[0] = 0.f;
+  pair[1] = 1.f;
+  if (co >= p.Cout) return;
+  if (EPI == 2 && p.bias != nullptr) pair[0] = p.bias[co];
+  if (EPI == 2 && p.oscale != nullptr) pair[1] = p.oscale[co];
+  if ((EPI == 0 || EPI == 3) && p.dbias != nullptr) pair[0] = p.dbias[co];
+}
+
 template <int BM, int BN, int EPI, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[BM / 64][BN / 64], char* lds_tiles,
                                               int w4, int lane, int m0, int n0, unsigned tile_m, bool valid,
-                                              const EpiPrefetch<BM, BN>* pre = nullptr) {
+                                              const EpiPrefetch<BM, BN>* pre = nullptr, const float* held = nullptr) {
+  // ``held`` (kernels that walk many tiles): the lane's per-column (bias, scale) pairs, [NT][2], loaded once by the
+  // caller -- a load per tile here waits behind the previous tile's stores, a memory round trip per tile.
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int EP_PITCH = WN * 2 + EP_PAD;
@@ -239,9 +252,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[B
   for (int nt = 0; nt < NT; ++nt) {
     const int co = n0 + wc * WN + nt * 32 + colq;
     float bias = 0.f, osc = 1.f;
-    if (EPI == 2 && p.bias != nullptr && co < p.Cout) bias = p.bias[co];
-    if (EPI == 2 && p.oscale != nullptr && co < p.Cout) osc = p.oscale[co];
-    if ((EPI == 0 || EPI == 3) && p.dbias != nullptr && co < p.Cout) bias = p.dbias[co];
+    if (held != nullptr) {
+      bias = held[nt * 2];
+      osc = held[nt * 2 + 1];
+    } else {
+      if (EPI == 2 && p.bias != nullptr && co < p.Cout) bias = p.bias[co];
+      if (EPI == 2 && p.oscale != nullptr && co < p.Cout) osc = p.oscale[co];
+      if ((EPI == 0 || EPI == 3) && p.dbias != nullptr && co < p.Cout) bias = p.dbias[co];
+    }
     const bool relu = EPI == 2 && p.relu != 0 && p.addend == nullptr;  // with a residual the ReLU follows the add
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll

@@ -165,6 +165,9 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
     ox[mt] = rem - oy[mt] * p.IW;
   }
 
+  float held[2];
+  epi_hold_column<EPI>(p, n0 + wc * WN + (lane & 31), held);
+
   wait_vmcnt<0>();   // the first patch (and the weights)
   __syncthreads();   // ... and the zero row, of every wave
 
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(ConvArgs p, int patch_r
       if (sum == 123.456f) p.y[0] = (bf16)sum;
     }
 #else
-    conv_epilogue<BM, BN, EPI, false>(p, acc, patch, wid, lane, m0, n0, tile, true, nullptr);
+    conv_epilogue<BM, BN, EPI, false>(p, acc, patch, wid, lane, m0, n0, tile, true, nullptr, held);
 #endif
     P3_CLK(4, "epilogue")
     if (NBUF == 2) cur ^= 1;

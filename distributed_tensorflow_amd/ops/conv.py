@@ -314,7 +314,7 @@ STREAM_OUT_BYTES = int(os.environ.get("DTFA_CONV_STREAM_OUT_BYTES", str(256 << 2
 def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, osx, oy0, ox0, isy, isx, B,
                   cin_magic, bias=None, relu=False, stats=False, addend=None, zero_taps=False, addend_mask=None,
                   bn_tap=None, oscale=None, ldo=0, omask=None, dbias=None, x2=None, addend_shift=(0, 0),
-                  stat_acc=None, near_taps=False):
+                  stat_acc=None, near_taps=False, grid_taps=None):
     M = B * oyn * oxn
     K = T * cin + (x2.shape[-1] if x2 is not None else 0)
     dense_out = osy == 1 and osx == 1 and oy0 == 0 and ox0 == 0 and oyn == oh and oxn == ow
@@ -394,6 +394,16 @@ def _launch_igemm(x, w2d, y, taps, T, ih, iw, cin, oh, ow, cout, oyn, oxn, osy, 
             found = tune.measure("igemm", key, _igemm_candidates(M, cout, K), launch, rule)
         if found is not None:   # entries measured before the reduction split existed carry no split: the rule adds it
             cfg = found if len(found) > 5 else tuple(found) + (pick_ksplit(found, M, cout, K),)
+    if (grid_taps is not None and p8_takes(cin, cout, grid_taps, ih, iw, oyn, oxn, isy, isx, M) and dense_out and x2 is None
+            and stat_acc is None and bn_tap is None and not _env_tile("DTFA_CONV_TILE")):
+        # conv_p8_kernel: persistent workgroups over 8-channel pixels, the pixels a tile touches staged once in LDS
+        part = None
+        if want_part:
+            part = torch.empty((L.dtfa_conv_stats_rows(M, 128), 2, cout), dtype=torch.float32, device=x.device)
+        a.stats = hipk.ptr(part)
+        a.tile_m_base = a.stat_row_base = a.tile_m_count = 0
+        hipk.check(L.dtfa_conv_p8(C.byref(a), grid_taps[0], grid_taps[1], hipk.stream()), "conv_p8")
+        return part
     if (_P3 and near_taps and cin in P3_CINS and cout <= P3_MAX_COUT and x2 is None and dense_out and iw <= P3_MAX_WIDTH
             and stat_acc is None and bn_tap is None and M >= _P3_MIN_ROWS and not _env_tile("DTFA_CONV_TILE")):
         cfg = (128, 64, 64, 3, 0, -1)   # conv_p3_kernel: persistent workgroups, weights in registers, pixel patches in LDS
@@ -415,6 +425,19 @@ P3_MAX_WIDTH = int(os.environ.get("DTFA_CONV_P3_MAX_WIDTH", "240"))
 P3_MAX_COUT = int(os.environ.get("DTFA_CONV_P3_MAX_COUT", "128"))   # (slices of 64 columns, one workgroup each)
 P3_CINS = tuple(int(c) for c in os.environ.get("DTFA_CONV_P3_CINS", "32,64").split(",") if c)   # input channels it is built for
 _P3_DGRAD = os.environ.get("DTFA_CONV_P3_DGRAD", "1") == "1"
+# conv_p8_kernel (csrc/hip/conv_p8.hip): strided layers over 8-channel pixels whose input is exactly stride times their
+# output (the pixel-pair stem of ResNet-50, 7 x 4 taps).  Not for 32 output channels, where half of its waves idle: the
+# flower CNN's first 3x3 / stride-2 layer measured 523 against 490 us.
+_P8 = os.environ.get("DTFA_CONV_P8", "1") == "1"
+_P8_TAPS = (9, 10, 27, 28)   # tap counts the kernel is instantiated for (5 or 14 k-steps of two taps)
+
+
+def p8_takes(cin: int, cout: int, grid, ih: int, iw: int, oh: int, ow: int, sy: int, sx: int, M: int) -> bool:
+    kh, kw = grid
+    return (_P8 and cin == 8 and 32 < cout <= 64 and kh * kw in _P8_TAPS and ih == oh * sy and iw == ow * sx and iw > kw
+            and M >= _P3_MIN_ROWS and hipk.lib().dtfa_conv_p8_buffer(iw, ow, sy, sx, kh, kw) > 0)
+
+
 _KSPLIT = os.environ.get("DTFA_CONV_KSPLIT", "auto")
 _KSPLIT_MAX_TILES = int(os.environ.get("DTFA_CONV_KSPLIT_MAX_TILES", "512"))
 
@@ -544,7 +567,7 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, plan: ConvPlan, bias: Optional[to
     part = _launch_igemm(x, w, y, plan.fwd_taps, plan.T, plan.ih, plan.iw, plan.cin, plan.oh, plan.ow, plan.cout,
                          plan.oh, plan.ow, 1, 1, 0, 0, plan.sy, plan.sx, B, plan.cin_magic, bias, relu, want_stats,
                          addend=residual, zero_taps=plan.is_pointwise, oscale=scale, ldo=ldo, omask=mask_out, x2=x2,
-                         stat_acc=stat_acc, near_taps=plan.near_taps)
+                         stat_acc=stat_acc, near_taps=plan.near_taps, grid_taps=(plan.kh, plan.kw))
     return y, part
 
 

@@ -85,6 +85,8 @@ def lib():
 class _Sigs:
     dtfa_conv_igemm = [C.POINTER(ConvArgs), c_int, c_int, c_int, c_int, c_void]
     dtfa_conv_igemm_ks = [C.POINTER(ConvArgs), c_int, c_int, c_int, c_int, c_int, c_void]
+    dtfa_conv_p8 = [C.POINTER(ConvArgs), c_int, c_int, c_void]
+    dtfa_conv_p8_buffer = [c_int, c_int, c_int, c_int, c_int, c_int]
     dtfa_conv_stats_rows = [c_int, c_int]
     dtfa_dense_skinny = [C.POINTER(SkinnyArgs), c_void]
     dtfa_conv_wgrad = [C.POINTER(WgradArgs), c_int, c_int, c_int, c_int, c_void]

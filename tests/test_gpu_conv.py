@@ -365,6 +365,49 @@ def test_same_size_3x3_by_the_persistent_kernel(case, monkeypatch):
         torch.testing.assert_close(got[0].float().cpu(), ref_y, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 24, 8, 64, 7, 4, 2, 1, (3, 3, 2, 1)),     # the pixel-pair stem, small
+                                  (3, 224, 112, 8, 64, 7, 4, 2, 1, (3, 3, 2, 1)),   # ... at its size: tiles cross rows, many tiles per workgroup
+                                  (2, 20, 18, 8, 40, 3, 3, 2, 2, "SAME"),           # odd tap count, idle columns
+                                  (5, 224, 224, 8, 64, 3, 3, 2, 2, "SAME"),         # stride 2 both ways at the flower CNN's image size
+                                  (1, 6, 10, 8, 48, 3, 3, 1, 1, "SAME"),            # unit stride, output narrower than a tile
+                                  (2, 10, 150, 8, 64, 7, 4, 2, 1, (3, 3, 2, 1))])   # rows wider than a tile
+def test_strided_layers_over_8_channel_pixels_by_the_persistent_kernel(case, monkeypatch):
+    """conv_p8_kernel (8 input channels, input = stride x output: the contiguous range of input pixels a 128-row tile
+    touches over all taps is staged in LDS once, a tap is a ds_read at the pixel's offset plus the tap's) gives the bits
+    of the ordinary kernel -- same reduction order -- with statistics and with the scale / bias / ReLU epilogue and a
+    residual."""
+    B, H, W, Cin, Cout, kh, kw, sy, sx, _ = case
+    x, w, pads = _mk(case, 41)
+    xb, wb = x.bfloat16().cuda(), w.bfloat16().cuda()
+    plan = cv.get_plan(H, W, Cin, Cout, kh, kw, sy, sx, pads, "cuda")
+    g = torch.Generator().manual_seed(42)
+    scale = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    shift = torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(B, plan.oh, plan.ow, Cout, generator=g).bfloat16().cuda()
+
+    def run():
+        y, part = cv.conv_fwd(xb, wb, plan, want_stats=True)
+        z, _ = cv.conv_fwd(xb, wb, plan, bias=shift, relu=True, scale=scale, residual=res)
+        return y, part, z
+
+    monkeypatch.setattr(cv.tune, "MODE", "off")
+    monkeypatch.setattr(cv, "_P3_MIN_ROWS", 0)
+    monkeypatch.setattr(cv, "_KSPLIT", "0")
+    monkeypatch.setattr(cv, "_P8", False)
+    want = run()
+    monkeypatch.setattr(cv, "_P8", True)
+    assert cv.p8_takes(Cin, Cout, (kh, kw), H, W, plan.oh, plan.ow, sy, sx, B * plan.oh * plan.ow)
+    got = run()
+    for a, b in zip(got, want):
+        if a.dtype == torch.bfloat16:
+            assert torch.equal(a, b)
+        else:
+            torch.testing.assert_close(a.double().sum(0), b.double().sum(0), rtol=1e-5, atol=1e-3)
+    if B * H * W <= 1 << 16:
+        ref_y = ref.conv2d(xb.float().cpu(), wb.float().cpu(), (sy, sx), pads)
+        torch.testing.assert_close(got[0].float().cpu(), ref_y, rtol=2e-2, atol=2e-2)
+
+
 def test_dgrad_masked_addend():
     """The dgrad epilogue adds only the elements of ``addend`` whose bit is set."""
     case = (2, 14, 14, 64, 32, 1, 1, 1, 1, "VALID")
