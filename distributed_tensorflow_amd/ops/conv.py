@@ -847,6 +847,17 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, plan: ConvPlan, out: Optional[
         hipk.check(L.dtfa_wgrad_reduce(slab.data_ptr(), slabs, n, f32, b16, 1 if accumulate else 0, hipk.stream()),
                    "wgrad_reduce")
         return out
+    if wgrad_p8_takes(plan, M) and not colsum:
+        # persistent kernel over 8-channel pixels: the whole 64 x 224 gradient in registers, two slabs per workgroup
+        slabs = L.dtfa_conv_wp8_slabs(M)
+        slab = hipk.workspace(x.device, slabs * n * 4)
+        a.slab = slab.data_ptr()
+        hipk.check(L.dtfa_conv_wp8(C.byref(a), plan.kh, plan.kw, hipk.stream()), "conv_wp8")
+        f32 = out.data_ptr() if out.dtype == torch.float32 else None
+        b16 = out.data_ptr() if out.dtype == torch.bfloat16 else None
+        hipk.check(L.dtfa_wgrad_reduce(slab.data_ptr(), slabs, n, f32, b16, 1 if accumulate else 0, hipk.stream()),
+                   "wgrad_reduce")
+        return out
     rule = pick_wgrad_tile(M, plan.cout, plan.K, plan.cin)
     cfg = rule
     if tune.MODE != "off" and not _env_tile("DTFA_WGRAD_TILE"):
@@ -873,6 +884,17 @@ _WGRAD_P3_MIN_ROWS = int(os.environ.get("DTFA_WGRAD_P3_MIN_ROWS", str(1 << 16)))
 
 def wgrad_p3_takes(plan: ConvPlan, M: int) -> bool:
     return (_WGRAD_P3 and plan.near_taps and plan.cin == 64 and plan.cout == 64 and 16 <= plan.iw <= 180
+            and M >= _WGRAD_P3_MIN_ROWS and not _env_tile("DTFA_WGRAD_TILE"))
+
+
+# conv_wp8_kernel (csrc/hip/conv_wp8.hip): the weight gradient of the pixel-pair stem (8-channel pixels, 7 x 4 taps, input
+# = stride x output) by persistent workgroups that stage the input range of a tile once.
+_WGRAD_P8 = os.environ.get("DTFA_WGRAD_P8", "1") == "1"
+
+
+def wgrad_p8_takes(plan: ConvPlan, M: int) -> bool:
+    return (_WGRAD_P8 and plan.cin == 8 and plan.cout == 64 and plan.T == 28 and plan.ih == plan.oh * plan.sy
+            and plan.iw == plan.ow * plan.sx and 32 <= plan.ow <= 160 and plan.iw > plan.kw
             and M >= _WGRAD_P3_MIN_ROWS and not _env_tile("DTFA_WGRAD_TILE"))
 
 

@@ -92,6 +92,8 @@ class _Sigs:
     dtfa_conv_wgrad = [C.POINTER(WgradArgs), c_int, c_int, c_int, c_int, c_void]
     dtfa_conv_wp3 = [C.POINTER(WgradArgs), c_void]
     dtfa_conv_wp3_slabs = [c_int]
+    dtfa_conv_wp8 = [C.POINTER(WgradArgs), c_int, c_int, c_void]
+    dtfa_conv_wp8_slabs = [c_int]
     dtfa_wgrad_reduce = [c_void, c_int, c_ll, c_void, c_void, c_int, c_void]
     dtfa_partial_reduce = [c_void, c_void, c_int, c_int, c_int, c_int, c_void]
     dtfa_bn_finalize = [c_void, c_int, c_int, c_float, c_float, c_void, c_void, c_void, c_void, c_void, c_void,

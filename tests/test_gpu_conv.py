@@ -180,6 +180,39 @@ def test_wgrad_of_same_size_3x3_by_the_persistent_kernel(case, monkeypatch):
     assert torch.equal(b16, got.bfloat16())
 
 
+@pytest.mark.parametrize("case", [(2, 64, 32), (3, 224, 112), (1, 40, 150), (2, 12, 33)])
+def test_wgrad_of_the_pixel_pair_stem_by_the_persistent_kernel(case, monkeypatch):
+    """conv_wp8_kernel (8-channel pixels, 7 x 4 taps, stride (2, 1), 64 output channels: every resident workgroup holds
+    the whole 64 x 224 gradient in registers and stages each tile's dY rows and contiguous input range once; both
+    operands through transposing LDS reads, out-of-image taps from a pixel of zeros) against fp32 autograd and against
+    the ordinary kernel.  The second case is the stem's own size with many tiles per workgroup, the third has rows wider
+    than a tile, the last a tile that ends past the tensor."""
+    B, H, W = case
+    full = (B, H, W, 8, 64, 7, 4, 2, 1, (3, 3, 2, 1))
+    x, w, pads = _mk(full, 51)
+    xr = x.bfloat16().float().requires_grad_(True)
+    wr = w.bfloat16().float().requires_grad_(True)
+    y = ref.conv2d(xr, wr, (2, 1), pads)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(52)).bfloat16()
+    y.backward(dy.float())
+    plan = cv.get_plan(H, W, 8, 64, 7, 4, 2, 1, pads, "cuda")
+    xb, dyb = xr.detach().bfloat16().cuda(), dy.cuda()
+    monkeypatch.setattr(cv.tune, "MODE", "off")
+    monkeypatch.setattr(cv, "_WGRAD_P8", False)
+    want = cv.conv_wgrad(xb, dyb, plan)
+    monkeypatch.setattr(cv, "_WGRAD_P8", True)
+    monkeypatch.setattr(cv, "_WGRAD_P3_MIN_ROWS", 0)
+    assert cv.wgrad_p8_takes(plan, B * plan.oh * plan.ow)
+    got = cv.conv_wgrad(xb, dyb, plan)
+    scale = wr.grad.abs().max().item()
+    assert (got.cpu() - wr.grad).abs().max().item() <= 2e-2 * scale
+    assert (got - want).abs().max().item() <= 1e-4 * scale          # both sum bf16 products in fp32, in different orders
+    assert torch.equal(got, cv.conv_wgrad(xb, dyb, plan))            # reproducible
+    acc = torch.ones_like(got)
+    cv.conv_wgrad(xb, dyb, plan, out=acc, accumulate=True)
+    torch.testing.assert_close(acc, got + 1.0, rtol=0, atol=1e-5 * scale + 1e-6)
+
+
 @pytest.mark.parametrize("tile", ["256,256,32,5", "256,256,64,3", "256,256,32,1"])
 @pytest.mark.parametrize("case", [(6, 14, 14, 256, 256, 3, 3, 1, 1, "SAME"), (5, 7, 9, 264, 520, 1, 1, 1, 1, "VALID"),
                                   (4, 15, 15, 256, 256, 3, 3, 2, 2, "SAME")])
