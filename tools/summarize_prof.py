@@ -23,8 +23,8 @@ def main():
     cats = {}
 
     def cat(n):
-        if "conv_igemm" in n or "conv_p3" in n: return "conv fwd/dgrad (implicit GEMM, MFMA)"
-        if "conv_wgrad" in n or "wgrad_reduce" in n: return "conv wgrad (+ split reduction)"
+        if "conv_igemm" in n or "conv_p3" in n or "conv_p8" in n: return "conv fwd/dgrad (implicit GEMM, MFMA)"
+        if "conv_wgrad" in n or "wgrad_reduce" in n or "conv_wp3" in n or "conv_wp8" in n: return "conv wgrad (+ split reduction)"
         if n.startswith("void bn_") or "bn_" in n or "col_partials" in n or "partial_reduce" in n: return "batch-norm (stats / apply / backward)"
         if "pool" in n or "gap_" in n: return "pooling"
         if "weight_permute" in n: return "dgrad weight permute"
