@@ -441,6 +441,35 @@ def test_strided_layers_over_8_channel_pixels_by_the_persistent_kernel(case, mon
         torch.testing.assert_close(got[0].float().cpu(), ref_y, rtol=2e-2, atol=2e-2)
 
 
+def test_convolutions_on_tensors_beyond_2_31_elements():
+    """The benchmark's per-GPU batch of 4096 makes the stage-1 activations of ResNet-50 3.3 G elements (4096 x 56 x 56 x
+    256).  The batch is the same 2048 images twice over: outputs and data gradients of the two halves must be the same
+    bits, and the weight gradient twice that of one half -- a kernel whose indices wrapped would break one of them."""
+    B, h = 4096, 2048
+    plan = cv.get_plan(56, 56, 64, 256, 1, 1, 1, 1, (0, 0, 0, 0), "cuda")
+    g = torch.Generator(device="cuda").manual_seed(61)
+    x1 = torch.randn(h, 56, 56, 64, device="cuda", generator=g).bfloat16()
+    x2 = torch.cat([x1, x1])
+    w = (torch.randn(256, 1, 1, 64, device="cuda", generator=g) * 0.1).bfloat16()
+    y, part = cv.conv_fwd(x2, w, plan, want_stats=True)
+    assert y.numel() > 1 << 31
+    assert torch.equal(y[:h], y[h:])
+    ref_rows = x1[:2].float().reshape(-1, 64) @ w.float().reshape(256, 64).t()      # the upper half against fp32
+    torch.testing.assert_close(y[h:h + 2].reshape(-1, 256).float(), ref_rows, rtol=2e-2, atol=2e-2)
+    dy1 = y[:h]
+    dx = cv.conv_dgrad(y, w, plan)                     # reads the 3.3 G element tensor
+    assert torch.equal(dx[:h], dx[h:])
+    dw2 = cv.conv_wgrad(x2, y, plan)
+    dw1 = cv.conv_wgrad(x1, dy1.contiguous(), plan)
+    assert (dw2 - 2 * dw1).abs().max().item() <= 1e-4 * dw2.abs().max().item()
+    plan2 = cv.get_plan(56, 56, 256, 64, 1, 1, 1, 1, (0, 0, 0, 0), "cuda")
+    w2 = (torch.randn(64, 1, 1, 256, device="cuda", generator=g) * 0.05).bfloat16()
+    dbig = cv.conv_dgrad(x2, w2, plan2, addend=y)      # writes one, with an addend of the same size
+    assert dbig.numel() > 1 << 31 and torch.equal(dbig[:h], dbig[h:])
+    del y, dx, dbig
+    torch.cuda.empty_cache()
+
+
 def test_dgrad_masked_addend():
     """The dgrad epilogue adds only the elements of ``addend`` whose bit is set."""
     case = (2, 14, 14, 64, 32, 1, 1, 1, 1, "VALID")
