@@ -140,6 +140,7 @@ class _Sigs:
     dtfa_set_hyper = [c_void, c_float, c_float, c_void]
     dtfa_weight_permute = [c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_void]
     dtfa_dropout = [c_void, c_void, c_ll, C.c_ulonglong, c_void, c_float, c_void]
+    dtfa_subsample = [c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_void]
     dtfa_p2p_create = [c_int, c_int, c_ll, C.c_double, C.POINTER(c_void)]
     dtfa_p2p_handle = [c_void, C.c_char_p]
     dtfa_p2p_connect = [c_void, C.c_char_p]

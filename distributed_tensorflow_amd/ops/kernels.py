@@ -604,6 +604,19 @@ def rng_step(device) -> torch.Tensor:
     return t
 
 
+def subsample(x: torch.Tensor, stride) -> torch.Tensor:
+    """``x[:, ::sy, ::sx, :]`` of a contiguous NHWC bf16 tensor as a new contiguous tensor (the block input on the pixel
+    grid of a strided projection shortcut)."""
+    hipk.require(x, BF16, "x")
+    sy, sx = stride
+    B, H, W, Cc = x.shape
+    if Cc % 8:
+        raise ValueError("subsample: channels must be a multiple of 8")
+    y = torch.empty((B, -(-H // sy), -(-W // sx), Cc), dtype=BF16, device=x.device)
+    hipk.check(hipk.lib().dtfa_subsample(x.data_ptr(), y.data_ptr(), B, H, W, Cc, sy, sx, hipk.stream()), "subsample")
+    return y
+
+
 def dropout(x: torch.Tensor, rate: float, seed: int) -> torch.Tensor:
     hipk.require(x, BF16, "x")
     y = torch.empty_like(x)

@@ -322,3 +322,14 @@ def test_bn_apply_from_column_sums_matches_finalize_then_apply(shape, relu, slic
     torch.testing.assert_close(rv1, rv0, rtol=1e-4, atol=1e-6)
     if sliced:
         assert torch.equal(b1[..., :8], b0[..., :8]) and torch.equal(b1[..., 8 + Cc:], b0[..., 8 + Cc:])
+
+
+@pytest.mark.parametrize("shape,stride", [((3, 8, 10, 64), (2, 2)), ((2, 7, 9, 256), (2, 2)), ((2, 9, 6, 40), (1, 2)),
+                                          ((1, 5, 5, 8), (3, 2))])
+def test_subsample_is_the_strided_slice(shape, stride):
+    """``K.subsample`` (the block input on the grid of a strided projection shortcut) against the slice it replaces."""
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(3)).bfloat16().cuda()
+    got = K.subsample(x, stride)
+    want = x[:, ::stride[0], ::stride[1], :].contiguous()
+    assert got.shape == want.shape and torch.equal(got, want)
+
