@@ -32,7 +32,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 # per-GPU batches sized for 288 GB of HBM: ResNet-50 at 1024 holds ~40 GB of activations and runs ~13 % more
 # images/s than at 256 (fixed per-layer costs and tile-quantisation tails amortise); same box, measured launch table
-# for each: 2048 (56 GB) 17 312, 4096 (111 GB) 17 776, 6144 (166 GB) 17 714 images/s.  At 4096 the stem output and the
+# for each: 2048 (56 GB) 17 312, 4096 (111 GB) 17 776 images/s; 6144 (166 GB) another +0.7 % (17 814 against 17 694 on one box).  At 4096 the stem output and the
 # stage-1 activations are 3.3 G elements each (tools/experiments/check_big_batch.py, check_big_ops.py: the kernels'
 # indices hold beyond 2^31).
 DEFAULT_BATCH = {"resnet50": 4096, "flower_cnn": 1024, "inception_v3_head": 256, "inception_v3_finetune": 512}
